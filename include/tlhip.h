@@ -1,0 +1,166 @@
+/*
+ * tlhip.h — C-ABI of libtlhip.so, the MI355X (gfx950) backend that replaces tinyllama.cpp's CUDA/cuBLAS
+ * backend (reference: cuda_kernels.h:104-643 + the raw cudaMalloc/cudaMemcpy/cublas* calls inlined in
+ * model.cpp, gpu_initialization.cpp, weight_management.cpp, kv_cache.cpp, gpu_memory_optimization.cpp).
+ *
+ * Conventions
+ *   - plain C: pointers and sizes only. `void* stream` is a hipStream_t (NULL = the default stream),
+ *     the counterpart of the reference's `cudaStream_t stream = 0` arguments.
+ *   - every function returns int: 0 = ok, non-zero = error; tl_last_error() gives the text. The C++ host
+ *     shim (tinyllama.cpp_amd/host/tl_backend.hpp) turns non-zero into std::runtime_error, which is the
+ *     reference's convention (gpuErrchk, cuda_kernels.h:66-82). Argument-validation failures return an
+ *     error instead of the reference's log-and-return-silently (cuda_kernels.cu:1335-1351).
+ *   - `*_dev` pointers are device pointers BORROWED from the caller; `*_host` are host pointers borrowed
+ *     for the duration of the call. tl_qweight / tl_model handles own their device memory.
+ *   - one host thread per handle, no re-entrancy (the reference's threading model).
+ *
+ * The big difference from the reference backend: weights stay QUANTIZED on the device. The reference
+ * dequantizes every GPU layer to FP32 on the host and calls cublasSgemm with N=1
+ * (weight_management.cpp:199-435, cuda_kernels.cu:291-314); here raw GGUF super-blocks are uploaded once,
+ * re-laid-out into 16-byte-aligned planes (tl_qweight) and consumed by block-dequant GEMV kernels.
+ */
+#ifndef TLHIP_H
+#define TLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ggml tensor type ids (reference ggml_types.h:21-42) */
+enum tl_type { TL_F32 = 0, TL_Q8_0 = 8, TL_Q4_K = 12, TL_Q6_K = 14, TL_Q8_K = 15 };
+
+typedef struct tl_qweight tl_qweight; /* one quantized [rows x cols] matrix resident in HBM */
+typedef struct tl_model tl_model;     /* a whole model + KV cache + workspaces + decode graph */
+
+/* ---- runtime: replaces the inline cudaSetDevice/cudaMalloc/cudaMemcpy/cudaFree/cudaStream*/
+/*      cublasCreate sites (215 of them) ---------------------------------------- */
+const char* tl_last_error(void);
+int tl_init(int device_ordinal);              /* hipSetDevice + sanity (gfx950 expected) */
+int tl_device_count(int* count_out);
+int tl_malloc(void** dev_out, size_t bytes);  /* cudaMalloc sites e.g. gpu_initialization.cpp:91-531 */
+int tl_free(void* dev);
+int tl_memset(void* dev, int value, size_t bytes, void* stream);
+int tl_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int tl_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int tl_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+int tl_stream_create(void** stream_out);
+int tl_stream_destroy(void* stream);
+int tl_stream_sync(void* stream);             /* cudaStreamSynchronize, model.cpp:1085 */
+int tl_device_sync(void);
+
+/* ---- quantized weights: replaces ensure_f32_concatenated_weights_loaded (weight_management.cpp:199-435)
+ *      and the BF16 embedding/lm_head uploads (gpu_initialization.cpp:182-342) --------------------- */
+/* host_blocks: rows*cols/block_elems raw GGUF blocks (quantization.h:57-124), row-major by output row.
+ * cols must be a multiple of 256 for the K-quants, of 32 for Q8_0 and F32. */
+int tl_qweight_upload(int type, const void* host_blocks, int rows, int cols, tl_qweight** out, void* stream);
+int tl_qweight_free(tl_qweight* w);
+int tl_qweight_info(const tl_qweight* w, int* type, int* rows, int* cols, size_t* device_bytes);
+
+/* Bit-exact dequantization on the device (parity hook for dequantize_q4_k_m / dequantize_q6_k /
+ * dequantize_q8_0_block / dequantize_q8_k, quantization.cpp:171-266, 1009-1052): rows [row0, row0+nrows)
+ * -> out_dev[nrows*cols] f32. Also what lookup_embedding (model_utils.cpp:11-182) becomes for one row. */
+int tl_dequantize_rows(const tl_qweight* w, int row0, int nrows, float* out_dev, void* stream);
+
+/* y[rows] = W x : replaces matvec_f32_f32_cuda (cuda_kernels.h:171) / matvec_bf16_f32_cuda (:424), on the
+ * quantized weights directly. FP32 accumulate; tolerance vs the reference's Kahan-double CPU dot is stated
+ * in tests/test_gpu_gemv.py. */
+int tl_matvec_q(const tl_qweight* w, const float* x_dev, float* y_dev, void* stream);
+/* Y[T][rows] = X[T][cols] W^T : replaces gemm_f32_f32_cuda / gemm_f32_to_bf16_f32_cuda via
+ * smart_gemm_batch_cuda (model.cpp:2141-2249) for batched prefill. */
+int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream);
+
+/* ---- glue operators (same argument meaning as the cuda_kernels.h wrappers they replace) ------- */
+/* rmsnorm_vector_cuda(_optimized) cuda_kernels.h:104,569: out = x*rsqrt(mean(x^2)+max(eps,1e-5))*w
+ * (the eps floor is the CPU path's, utils.cpp:666-667, which is the parity target) */
+int tl_rmsnorm_vector(const float* x_dev, const float* weight_dev, float* out_dev, int n, float eps, void* stream);
+/* rmsnorm_batch_cuda cuda_kernels.h:124 (plain eps, utils.cpp:640) */
+int tl_rmsnorm_batch(float* out_dev, const float* in_dev, const float* weight_dev, int num_tokens, int hidden_size,
+                     float eps, void* stream);
+/* RoPE table of gpu_initialization.cpp:48-58, computed on the host (glibc cosf/sinf/powf, exactly as the
+ * reference) and uploaded: table_dev[max_pos][head_dim/2][2] */
+int tl_rope_table_upload(float* table_dev, int max_pos, int head_dim, float theta, void* stream);
+/* rope_cuda cuda_kernels.h:239 */
+int tl_rope(float* vec_dev, int num_heads, int head_dim, const float* freqs_cis_dev, int pos, int max_pos,
+            int use_adjacent_pairing, void* stream);
+/* rope_batch_cuda cuda_kernels.h:490 */
+int tl_rope_batch(float* q_batch_dev, float* k_batch_dev, const float* freqs_cis_dev, int num_tokens,
+                  int num_q_heads, int num_kv_heads, int head_dim, int start_pos, int max_pos,
+                  int use_adjacent_pairing, void* stream);
+/* update_kv_cache_cuda cuda_kernels.h:344 — cache layout [max_seq_len][num_kv_heads][head_dim] */
+int tl_update_kv_cache(float* cache_base_dev, const float* kv_vector_dev, int pos, int kv_head_idx,
+                       int max_seq_len, int num_kv_heads, int head_dim, void* stream);
+/* update_kv_cache_batch_cuda cuda_kernels.h:537 */
+int tl_update_kv_cache_batch(float* cache_base_dev, const float* kv_batch_dev, int start_pos, int num_tokens,
+                             int num_kv_heads, int head_dim, int cache_max_seq_len, void* stream);
+/* attention_cuda / attention_cuda_optimized cuda_kernels.h:259,607 (math of model.cpp:632-663) */
+int tl_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev, float* out_dev,
+                 int num_heads, int current_seq_len, int head_dim, float scale, int cache_max_seq_len,
+                 int cache_num_kv_heads, void* stream);
+/* attention_batch_prefill_cuda cuda_kernels.h:498 (math of cpu_attention.cpp:91-201), causal from the cache */
+int tl_attention_batch_prefill(const float* q_batch_dev, const float* k_cache_dev, const float* v_cache_dev,
+                               float* out_batch_dev, int num_tokens, int start_pos, int cache_max_seq_len,
+                               int num_q_heads, int num_kv_heads, int head_dim, float scale, void* stream);
+/* add_residual_cuda / add_vectors_cuda / add_residual_batch_cuda cuda_kernels.h:317,329,517 */
+int tl_add_residual(const float* a_dev, const float* b_dev, float* out_dev, size_t n, void* stream);
+/* swiglu_cuda cuda_kernels.h:379 (decode form, model.cpp:734-735) / swiglu_batch_cuda :482
+ * (batch form, cpu_batch_processor.cpp:252-256) */
+int tl_swiglu(const float* gate_dev, const float* up_dev, float* out_dev, size_t n, int batch_form, void* stream);
+/* lookup_embedding_cuda cuda_kernels.h:408, from the quantized table */
+int tl_lookup_embedding(const tl_qweight* table, int token_id, float* out_dev, void* stream);
+/* argmax + repetition penalty on the device (api.cpp:73-97,134-136): first maximal index */
+int tl_argmax(const float* logits_dev, int n, int* result_dev, void* stream);
+
+/* ---- whole-model engine: what TinyLlamaModel::forward_device (model.cpp:810-1090) + KVCache
+ *      (model.h:132-230, kv_cache.cpp:10-169) + the persistent workspaces (gpu_memory_optimization.cpp:8-52)
+ *      become ------------------------------------------------------------------------------------- */
+typedef struct tl_model_config {
+  int hidden_size, intermediate_size, num_attention_heads, num_key_value_heads, num_hidden_layers, vocab_size;
+  int max_position_embeddings; /* RoPE table rows and KV cache length */
+  float rms_norm_eps, rope_theta;
+  int tp_rank, tp_size; /* tensor parallel shard this handle holds (1 = unsharded) */
+} tl_model_config;
+
+/* tensor kinds for tl_model_set_tensor; names are the GGUF tensor names the reference consumes
+ * (weight_management.cpp:732-960) */
+enum tl_tensor_kind {
+  TL_T_ATTN_Q = 0, TL_T_ATTN_K, TL_T_ATTN_V, TL_T_ATTN_OUTPUT, TL_T_FFN_GATE, TL_T_FFN_UP, TL_T_FFN_DOWN,
+  TL_T_ATTN_NORM, TL_T_FFN_NORM, TL_T_TOKEN_EMBD, TL_T_OUTPUT_NORM, TL_T_OUTPUT
+};
+
+int tl_model_create(const tl_model_config* cfg, tl_model** out);
+int tl_model_free(tl_model* m);
+/* host_data: raw GGUF tensor bytes of the FULL (unsharded) tensor; with tp_size>1 the handle keeps only its
+ * shard (row split for q/k/v/gate/up/output, column split for attn_output/ffn_down). layer = -1 for globals. */
+int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, const void* host_data, int rows, int cols);
+/* allocate KV cache + workspaces, upload the RoPE table, check every tensor is present */
+int tl_model_finalize(tl_model* m);
+int tl_model_reset_kv(tl_model* m); /* KVCache::clear_data (model.h:182-197) */
+/* One decode step = lookup_embedding + forward_device for one token at `pos`; logits_host may be NULL.
+ * next_token_host (may be NULL) receives argmax(logits) computed on the device (greedy, no penalty). */
+int tl_model_decode(tl_model* m, int token_id, int pos, float* logits_host, int* next_token_host);
+/* Greedy generation entirely on the device: feeds argmax back as the next input for n_steps steps starting
+ * at (first_token, start_pos); writes the n_steps sampled ids. Repetition penalty as api.cpp:86-97 over the
+ * last 64 ids of `history` + what is generated (penalty <= 1: off). */
+int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
+                             const int* history_host, int n_history, int* out_ids_host);
+/* batched prefill of T prompt tokens starting at start_pos (forward_device_batch_prefill, model.cpp:1526-1862);
+ * last_logits_host[vocab] (may be NULL) = logits of the last token; all_logits_host[T][vocab] may be NULL */
+int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
+                     float* all_logits_host);
+/* device pointers into the model's state, for parity tests and for hosts that keep using the operator-level
+ * calls: which = 0 K cache, 1 V cache of `layer` ([max_pos][n_kv_heads_local][head_dim] f32), 2 = x (hidden) */
+int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out);
+/* algorithmic bytes one decode step at position pos must move on this rank (SURVEY §8d B_tok) */
+int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, double* kv_bytes);
+/* tensor-parallel wiring: RCCL communicator over xGMI; unique_id is ncclUniqueId bytes (128) produced by
+ * tl_tp_unique_id on rank 0 and broadcast by the host (torch.distributed) */
+int tl_tp_unique_id(void* id_out_128);
+int tl_model_tp_init(tl_model* m, const void* unique_id_128);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

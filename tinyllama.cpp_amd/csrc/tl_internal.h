@@ -1,0 +1,98 @@
+// tl_internal.h — shared declarations inside libtlhip.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "tlhip.h"
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void tl_set_error(const char* fmt, ...);
+#define TL_HIP(expr)                                                                          \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      tl_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+      return 1;                                                                               \
+    }                                                                                         \
+  } while (0)
+#define TL_REQUIRE(cond, ...)    \
+  do {                           \
+    if (!(cond)) {               \
+      tl_set_error(__VA_ARGS__); \
+      return 2;                  \
+    }                            \
+  } while (0)
+#define TL_TRY(expr)          \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+// ---- device layout of one quantized matrix -----------------------------------------------------------
+// The GGUF blocks (quantization.h:57-124) are split at upload into 16-byte-aligned planes, row-major by
+// output row, so that one wave-wide 16 B/lane load is a contiguous, aligned 1 KiB and every lane's 16 B
+// of payload is exactly one 32-weight "chunk" over 32 CONSECUTIVE columns:
+//
+//   Q4_K  p0 qs'  [rows][cols/2]        chunk = 16 B: dword w byte t = (weight 8w+t) | (weight 8w+4+t)<<4
+//         p1 hdr' [rows][cols/256][16]  {d:f16 | dmin:f16<<16, sc_lo4[8 x 4b], m_lo4[8 x 4b],
+//                                         sc_hi2[8 x 2b] | m_hi2[8 x 2b]<<16}
+//   Q6_K  p0 ql'  [rows][cols/2]        low nibbles, same nibble order as Q4_K
+//         p1 qh'  [rows][cols/4]        chunk = 8 B: dword v byte t bits 2g..2g+1 = high 2 bits of weight 16v+4g+t
+//         p2 sc   [rows][cols/16] i8    natural order
+//         p3 d    [rows][cols/256] f16
+//   Q8_0  p0 qs   [rows][cols] i8, p1 d [rows][cols/32] f16
+//   Q8_K  p0 qs   [rows][cols] i8, p1 d [rows][cols/256] f16        (bsums are not needed and not kept)
+//   F32   p0      [rows][cols] f32
+// Total device bytes == GGUF bytes (Q8_K: minus the 32 B of bsums per block).
+struct tl_qweight {
+  int type, rows, cols;
+  size_t bytes;  // device bytes held
+  void* base;    // single allocation
+  uint8_t *p0, *p1, *p2, *p3;
+};
+
+struct QW {  // by-value kernel argument
+  const uint8_t *p0, *p1, *p2, *p3;
+  int rows, cols, type;
+};
+static inline QW qw_view(const tl_qweight* w) {
+  return QW{w->p0, w->p1, w->p2, w->p3, w->rows, w->cols, w->type};
+}
+
+size_t tl_type_block_bytes(int type);
+int tl_type_block_elems(int type);
+// device bytes of a [rows x cols] matrix of `type` in the plane layout
+size_t tl_qweight_device_bytes(int type, int rows, int cols);
+// builds a tl_qweight over caller-provided storage [base, base+bytes) from raw GGUF blocks on the host
+int tl_qweight_build(int type, const void* host_blocks, int rows, int cols, tl_qweight* w, hipStream_t s);
+
+// ---- launchers shared between the operator-level C-ABI and the model engine ---------------------------
+// GEMV over 1..3 matrices that share the input vector (q|k|v in one launch), with optional fused
+// RMSNorm prologue, residual epilogue, or gate/up SwiGLU pairing; see tl_gemv.hip
+struct GemvSeg {
+  QW w;
+  float* out;
+};
+struct GemvArgs {
+  GemvSeg seg[3];
+  int nseg;
+  int pair;             // 1: out0[r] = swiglu(seg0[r].x, seg1[r].x)  (decode form, model.cpp:734-735)
+  int cols;             // shared K
+  const float* x;       // [cols]
+  const float* norm_w;  // != NULL: x := rmsnorm_vector(x, norm_w, eps) first (utils.cpp:648-673)
+  float eps;
+  const float* resid;   // != NULL: out0[r] = resid[r] + y[r]   (single segment only)
+};
+int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
+
+int tl_launch_rmsnorm(const float* x, const float* w, float* out, int T, int n, float eps, int floor_eps,
+                      hipStream_t s);
+int tl_launch_dequant_rows(const tl_qweight* w, const int* row_index_dev, int row0, int nrows, float* out,
+                           hipStream_t s);
+int tl_launch_rope_kv(float* q, float* k, const float* v, float* kcache, float* vcache, const float* table, int nq,
+                      int nkv, int hd, const int* pos_dev, int max_pos, hipStream_t s);
+int tl_launch_attn_decode(const float* q, const float* kc, const float* vc, float* out, int nh, int nkv, int hd,
+                          int seq_len, const int* pos_dev, int max_seq, float scale, hipStream_t s);
+int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, const int* n_hist_dev, float penalty,
+                     hipStream_t s);

@@ -1,0 +1,461 @@
+// tl_model.hip — the whole-model engine behind the C-ABI: what TinyLlamaModel::forward_device
+// (model.cpp:810-1090), KVCache (model.h:132-230, kv_cache.cpp:10-169), the persistent workspaces
+// (gpu_memory_optimization.cpp:8-52) and the greedy part of the generate loop (api.cpp:696-813) become on
+// MI355X.
+//
+// Design (MI355X-first, not the reference's call pattern):
+//   - weights stay quantized in HBM in the plane layout (tl_internal.h), uploaded once;
+//   - one decode step is 2 + 6*L kernels: embed | per layer {norm+QKV GEMV, RoPE+KV write, attention,
+//     O GEMV+residual, norm+gate/up GEMV+SwiGLU, down GEMV+residual} | norm+lm_head GEMV | penalty+argmax+advance;
+//   - the step is captured ONCE into a hipGraph. Token id, position and the generated-id history live in a small
+//     device-side state block that the last kernel of a step updates, so the graph is replayed back-to-back with
+//     no host round trip, no per-token D2H of logits and no graph update (the reference syncs the stream and copies
+//     vocab*4 bytes to the host every token, model.cpp:1085-1088).
+#include <string.h>
+
+#include <vector>
+
+#include "tl_internal.h"
+
+namespace {
+
+struct DevState {  // mirrors the device-side step state
+  int token;
+  int pos;
+  int n_hist;
+  float penalty;
+};
+constexpr int kStateHeaderInts = 4;
+
+struct LayerW {
+  tl_qweight* q[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* attn_norm = nullptr;
+  float* ffn_norm = nullptr;
+};
+
+}  // namespace
+
+struct tl_model {
+  tl_model_config cfg;
+  int head_dim = 0, kv_dim = 0;
+  std::vector<LayerW> layers;
+  tl_qweight* tok = nullptr;
+  tl_qweight* out = nullptr;
+  float* out_norm = nullptr;
+  // KV cache: per layer [max_pos][n_kv_heads][head_dim] f32 (the reference's layout, model.cpp:622-625)
+  float* kv_base = nullptr;
+  size_t kv_layer_elems = 0;
+  // workspaces
+  float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *h = nullptr, *logits = nullptr;
+  float* rope = nullptr;
+  int* state = nullptr;  // DevState header + history ring
+  int hist_cap = 0;
+  hipStream_t stream = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  bool finalized = false;
+  double weight_bytes = 0.0;  // algorithmic (GGUF) bytes of all per-token matrices incl. one embedding row
+  float* kc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems; }
+  float* vc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems + kv_layer_elems; }
+};
+
+static int upload_f32(float** dst, const void* host, size_t n, hipStream_t s) {
+  if (*dst) {
+    TL_HIP(hipFree(*dst));
+    *dst = nullptr;
+  }
+  TL_HIP(hipMalloc(dst, n * sizeof(float)));
+  TL_HIP(hipMemcpyAsync(*dst, host, n * sizeof(float), hipMemcpyHostToDevice, s));
+  TL_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int tl_model_create(const tl_model_config* cfg, tl_model** out) {
+  TL_REQUIRE(cfg && out, "tl_model_create: null argument");
+  TL_REQUIRE(cfg->hidden_size > 0 && cfg->intermediate_size > 0 && cfg->num_attention_heads > 0 &&
+                 cfg->num_key_value_heads > 0 && cfg->num_hidden_layers > 0 && cfg->vocab_size > 0 &&
+                 cfg->max_position_embeddings > 0,
+             "tl_model_create: non-positive dimension in config");
+  TL_REQUIRE(cfg->hidden_size % cfg->num_attention_heads == 0, "tl_model_create: hidden_size %d not divisible by %d heads",
+             cfg->hidden_size, cfg->num_attention_heads);
+  TL_REQUIRE(cfg->num_attention_heads % cfg->num_key_value_heads == 0, "tl_model_create: %d heads not divisible by %d kv heads",
+             cfg->num_attention_heads, cfg->num_key_value_heads);
+  TL_REQUIRE(cfg->hidden_size % 32 == 0 && cfg->intermediate_size % 32 == 0, "tl_model_create: sizes must be multiples of 32");
+  const int tp = cfg->tp_size <= 0 ? 1 : cfg->tp_size;
+  TL_REQUIRE(tp == 1, "tl_model_create: tp_size %d: tensor parallel shards are not wired up in this build", tp);
+  tl_model* m = new tl_model();
+  m->cfg = *cfg;
+  m->cfg.tp_size = tp;
+  m->cfg.tp_rank = 0;
+  m->head_dim = cfg->hidden_size / cfg->num_attention_heads;
+  m->kv_dim = m->head_dim * cfg->num_key_value_heads;
+  m->layers.resize(cfg->num_hidden_layers);
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete m;
+    tl_set_error("tl_model_create: hipStreamCreate failed: %s", hipGetErrorString(e));
+    return 1;
+  }
+  *out = m;
+  return 0;
+}
+
+extern "C" int tl_model_free(tl_model* m) {
+  if (!m) return 0;
+  if (m->stream) hipStreamSynchronize(m->stream);
+  if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
+  if (m->graph) hipGraphDestroy(m->graph);
+  for (auto& l : m->layers) {
+    for (auto*& w : l.q) tl_qweight_free(w);
+    hipFree(l.attn_norm);
+    hipFree(l.ffn_norm);
+  }
+  tl_qweight_free(m->tok);
+  tl_qweight_free(m->out);
+  float* bufs[] = {m->out_norm, m->kv_base, m->x, m->q, m->k, m->v, m->att, m->h, m->logits, m->rope};
+  for (float* b : bufs) hipFree(b);
+  hipFree(m->state);
+  if (m->stream) hipStreamDestroy(m->stream);
+  delete m;
+  return 0;
+}
+
+extern "C" int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, const void* host_data, int rows,
+                                   int cols) {
+  TL_REQUIRE(m && host_data, "tl_model_set_tensor: null argument");
+  TL_REQUIRE(!m->finalized, "tl_model_set_tensor: model already finalized");
+  const tl_model_config& c = m->cfg;
+  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
+  const int qd = H, kvd = m->kv_dim;
+  if (kind == TL_T_ATTN_NORM || kind == TL_T_FFN_NORM || kind == TL_T_OUTPUT_NORM) {
+    // norms must be F32 tensors (weight_management.cpp:838,926,957)
+    TL_REQUIRE(type == TL_F32, "tl_model_set_tensor: norm weights must be F32 (got type %d)", type);
+    TL_REQUIRE((size_t)rows * cols == (size_t)H, "tl_model_set_tensor: norm weight has %d x %d elements, expected %d", rows, cols, H);
+    if (kind == TL_T_OUTPUT_NORM) return upload_f32(&m->out_norm, host_data, H, m->stream);
+    TL_REQUIRE(layer >= 0 && layer < c.num_hidden_layers, "tl_model_set_tensor: layer %d out of range", layer);
+    return upload_f32(kind == TL_T_ATTN_NORM ? &m->layers[layer].attn_norm : &m->layers[layer].ffn_norm, host_data, H,
+                      m->stream);
+  }
+  int er = 0, ec = 0;
+  tl_qweight** slot = nullptr;
+  switch (kind) {
+    case TL_T_ATTN_Q: er = qd; ec = H; break;
+    case TL_T_ATTN_K: er = kvd; ec = H; break;
+    case TL_T_ATTN_V: er = kvd; ec = H; break;
+    case TL_T_ATTN_OUTPUT: er = H; ec = qd; break;
+    case TL_T_FFN_GATE: er = I; ec = H; break;
+    case TL_T_FFN_UP: er = I; ec = H; break;
+    case TL_T_FFN_DOWN: er = H; ec = I; break;
+    case TL_T_TOKEN_EMBD: er = V; ec = H; slot = &m->tok; break;
+    case TL_T_OUTPUT: er = V; ec = H; slot = &m->out; break;
+    default: TL_REQUIRE(false, "tl_model_set_tensor: unknown tensor kind %d", kind);
+  }
+  if (!slot) {
+    TL_REQUIRE(layer >= 0 && layer < c.num_hidden_layers, "tl_model_set_tensor: layer %d out of range", layer);
+    slot = &m->layers[layer].q[kind];
+  }
+  TL_REQUIRE(rows == er && cols == ec, "tl_model_set_tensor: kind %d has shape %d x %d, config expects %d x %d", kind,
+             rows, cols, er, ec);
+  if (*slot) {
+    tl_qweight_free(*slot);
+    *slot = nullptr;
+  }
+  return tl_qweight_upload(type, host_data, rows, cols, slot, m->stream);
+}
+
+static double gguf_bytes(const tl_qweight* w, int rows) {
+  return (double)rows * w->cols / tl_type_block_elems(w->type) * (double)tl_type_block_bytes(w->type);
+}
+
+// ---- the per-step state + final kernel ------------------------------------------------------------------
+// penalty (api.cpp:86-97) + first-max arg-max (api.cpp:79,135) + advance of the device-side state
+__global__ __launch_bounds__(1024) void sample_advance_kernel(float* __restrict__ logits, int n, int* __restrict__ state,
+                                                              int hist_cap) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  int* hist = state + kStateHeaderInts;
+  const int n_hist = state[2];
+  const float penalty = __int_as_float(state[3]);
+  if (penalty > 1.0f) {
+    if (threadIdx.x == 0) {
+      const int start = n_hist > 64 ? n_hist - 64 : 0;
+      for (int i = start; i < n_hist; ++i) {
+        const int id = hist[i];
+        if (id < 0 || id >= n) continue;
+        const float l = logits[id];
+        logits[id] = (l > 0.0f) ? l / penalty : l * penalty;
+      }
+    }
+    __syncthreads();
+  }
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = logits[i];
+    if (v > best) {
+      best = v;
+      idx = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(idx, o);
+    if (ov > best || (ov == best && oi < idx)) {
+      best = ov;
+      idx = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    bv[threadIdx.x >> 6] = best;
+    bi[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) {
+        best = bv[w];
+        idx = bi[w];
+      }
+    if (idx == 0x7fffffff) idx = 0;
+    state[0] = idx;                            // next input token
+    state[1] = state[1] + 1;                   // next position
+    if (n_hist < hist_cap) hist[n_hist] = idx; // generated ids, in order
+    state[2] = n_hist + 1;
+  }
+}
+
+static int enqueue_step(tl_model* m) {
+  const tl_model_config& c = m->cfg;
+  hipStream_t s = m->stream;
+  const int* tok_dev = m->state;
+  const int* pos_dev = m->state + 1;
+  const float scale = 1.0f / sqrtf((float)m->head_dim);
+  TL_TRY(tl_launch_dequant_rows(m->tok, tok_dev, 0, 1, m->x, s));
+  for (int l = 0; l < c.num_hidden_layers; ++l) {
+    LayerW& L = m->layers[l];
+    GemvArgs a = {};
+    a.seg[0] = {qw_view(L.q[TL_T_ATTN_Q]), m->q};
+    a.seg[1] = {qw_view(L.q[TL_T_ATTN_K]), m->k};
+    a.seg[2] = {qw_view(L.q[TL_T_ATTN_V]), m->v};
+    a.nseg = 3;
+    a.cols = c.hidden_size;
+    a.x = m->x;
+    a.norm_w = L.attn_norm;
+    a.eps = c.rms_norm_eps;
+    TL_TRY(tl_launch_gemv(a, s));
+    TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, c.num_attention_heads,
+                             c.num_key_value_heads, m->head_dim, pos_dev, c.max_position_embeddings, s));
+    TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, c.num_attention_heads, c.num_key_value_heads,
+                                 m->head_dim, 0, pos_dev, c.max_position_embeddings, scale, s));
+    GemvArgs o = {};
+    o.seg[0] = {qw_view(L.q[TL_T_ATTN_OUTPUT]), m->x};
+    o.nseg = 1;
+    o.cols = c.hidden_size;
+    o.x = m->att;
+    o.resid = m->x;
+    TL_TRY(tl_launch_gemv(o, s));
+    GemvArgs g = {};
+    g.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), m->h};
+    g.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), nullptr};
+    g.nseg = 2;
+    g.pair = 1;
+    g.cols = c.hidden_size;
+    g.x = m->x;
+    g.norm_w = L.ffn_norm;
+    g.eps = c.rms_norm_eps;
+    TL_TRY(tl_launch_gemv(g, s));
+    GemvArgs d = {};
+    d.seg[0] = {qw_view(L.q[TL_T_FFN_DOWN]), m->x};
+    d.nseg = 1;
+    d.cols = c.intermediate_size;
+    d.x = m->h;
+    d.resid = m->x;
+    TL_TRY(tl_launch_gemv(d, s));
+  }
+  GemvArgs f = {};
+  f.seg[0] = {qw_view(m->out), m->logits};
+  f.nseg = 1;
+  f.cols = c.hidden_size;
+  f.x = m->x;
+  f.norm_w = m->out_norm;
+  f.eps = c.rms_norm_eps;
+  TL_TRY(tl_launch_gemv(f, s));
+  sample_advance_kernel<<<1, 1024, 0, s>>>(m->logits, c.vocab_size, m->state, m->hist_cap);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+static int set_state(tl_model* m, int token, int pos, float penalty, const int* hist, int n_hist) {
+  std::vector<int> hbuf(kStateHeaderInts + (n_hist > 0 ? n_hist : 0));
+  hbuf[0] = token;
+  hbuf[1] = pos;
+  hbuf[2] = n_hist;
+  memcpy(&hbuf[3], &penalty, sizeof(float));
+  if (n_hist > 0) memcpy(&hbuf[kStateHeaderInts], hist, sizeof(int) * (size_t)n_hist);
+  TL_HIP(hipMemcpyAsync(m->state, hbuf.data(), hbuf.size() * sizeof(int), hipMemcpyHostToDevice, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));  // hbuf is a stack-lifetime buffer
+  return 0;
+}
+
+extern "C" int tl_model_finalize(tl_model* m) {
+  TL_REQUIRE(m, "tl_model_finalize: null handle");
+  if (m->finalized) return 0;
+  const tl_model_config& c = m->cfg;
+  TL_REQUIRE(m->tok && m->out && m->out_norm, "tl_model_finalize: token_embd / output / output_norm missing "
+             "(the reference has no tied-embedding fallback either, model.cpp:797)");
+  m->weight_bytes = gguf_bytes(m->tok, 1) + gguf_bytes(m->out, m->out->rows);
+  for (int l = 0; l < c.num_hidden_layers; ++l) {
+    const LayerW& L = m->layers[l];
+    for (int k = 0; k < 7; ++k) {
+      TL_REQUIRE(L.q[k], "tl_model_finalize: layer %d is missing tensor kind %d", l, k);
+      m->weight_bytes += gguf_bytes(L.q[k], L.q[k]->rows);
+    }
+    TL_REQUIRE(L.attn_norm && L.ffn_norm, "tl_model_finalize: layer %d is missing a norm weight", l);
+  }
+  const size_t H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size, P = c.max_position_embeddings;
+  m->kv_layer_elems = P * (size_t)m->kv_dim;
+  TL_HIP(hipMalloc(&m->kv_base, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers));
+  TL_HIP(hipMemsetAsync(m->kv_base, 0, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers, m->stream));
+  TL_HIP(hipMalloc(&m->x, sizeof(float) * H));
+  TL_HIP(hipMalloc(&m->q, sizeof(float) * H));
+  TL_HIP(hipMalloc(&m->k, sizeof(float) * m->kv_dim));
+  TL_HIP(hipMalloc(&m->v, sizeof(float) * m->kv_dim));
+  TL_HIP(hipMalloc(&m->att, sizeof(float) * H));
+  TL_HIP(hipMalloc(&m->h, sizeof(float) * I));
+  TL_HIP(hipMalloc(&m->logits, sizeof(float) * V));
+  TL_HIP(hipMalloc(&m->rope, sizeof(float) * P * m->head_dim));
+  TL_TRY(tl_rope_table_upload(m->rope, (int)P, m->head_dim, c.rope_theta, m->stream));
+  m->hist_cap = (int)P + 64;
+  TL_HIP(hipMalloc(&m->state, sizeof(int) * (kStateHeaderInts + m->hist_cap)));
+  TL_HIP(hipMemsetAsync(m->state, 0, sizeof(int) * (kStateHeaderInts + m->hist_cap), m->stream));
+  // one eager step (position 0) outside capture: sets kernel attributes and validates every launch
+  TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));
+  TL_TRY(enqueue_step(m));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  // capture the step once
+  TL_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_step(m);
+  hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+  if (rc != 0) return rc;
+  TL_HIP(e);
+  TL_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+  // the warm-up step wrote position 0 of the cache: clear it again
+  TL_HIP(hipMemsetAsync(m->kv_base, 0, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  m->finalized = true;
+  return 0;
+}
+
+extern "C" int tl_model_reset_kv(tl_model* m) {
+  TL_REQUIRE(m && m->finalized, "tl_model_reset_kv: model not finalized");
+  TL_HIP(hipMemsetAsync(m->kv_base, 0, sizeof(float) * 2 * m->kv_layer_elems * m->cfg.num_hidden_layers, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits_host, int* next_token_host) {
+  TL_REQUIRE(m && m->finalized, "tl_model_decode: model not finalized");
+  TL_REQUIRE(pos >= 0 && pos < m->cfg.max_position_embeddings, "tl_model_decode: pos %d outside [0,%d)", pos,
+             m->cfg.max_position_embeddings);
+  TL_TRY(set_state(m, token_id, pos, 1.0f, nullptr, 0));
+  TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+  if (logits_host)
+    TL_HIP(hipMemcpyAsync(logits_host, m->logits, sizeof(float) * (size_t)m->cfg.vocab_size, hipMemcpyDeviceToHost, m->stream));
+  if (next_token_host) TL_HIP(hipMemcpyAsync(next_token_host, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
+                                        const int* history_host, int n_history, int* out_ids_host) {
+  TL_REQUIRE(m && m->finalized, "tl_model_generate_greedy: model not finalized");
+  TL_REQUIRE(n_steps >= 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
+             "tl_model_generate_greedy: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + n_steps,
+             m->cfg.max_position_embeddings);
+  TL_REQUIRE(n_history >= 0 && (n_history == 0 || history_host), "tl_model_generate_greedy: bad history");
+  // only the last 64 ids matter for the penalty window (api.cpp:88-90)
+  const int keep = n_history > 64 ? 64 : n_history;
+  TL_REQUIRE(keep + n_steps <= m->hist_cap, "tl_model_generate_greedy: %d steps exceed the id history capacity", n_steps);
+  TL_TRY(set_state(m, first_token, start_pos, penalty, history_host ? history_host + (n_history - keep) : nullptr, keep));
+  for (int i = 0; i < n_steps; ++i) TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+  if (n_steps > 0 && out_ids_host)
+    TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
+                          hipMemcpyDeviceToHost, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// Batched prefill. This build runs the T prompt tokens as T replays of the decode graph (token ids fed from the
+// host-provided list); positions, KV contents and logits are those of the token-by-token path, which the
+// reference's batched CPU path reproduces to ~1e-6.
+__global__ void set_token_kernel(int* state, const int* tokens, int i) { state[0] = tokens[i]; }
+
+extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos,
+                                float* last_logits_host, float* all_logits_host) {
+  TL_REQUIRE(m && m->finalized, "tl_model_prefill: model not finalized");
+  TL_REQUIRE(tokens_host && num_tokens > 0, "tl_model_prefill: empty prompt");
+  TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m->cfg.max_position_embeddings,
+             "tl_model_prefill: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + num_tokens,
+             m->cfg.max_position_embeddings);
+  int* toks_dev = nullptr;
+  TL_HIP(hipMalloc(&toks_dev, sizeof(int) * (size_t)num_tokens));
+  hipError_t e = hipMemcpyAsync(toks_dev, tokens_host, sizeof(int) * (size_t)num_tokens, hipMemcpyHostToDevice, m->stream);
+  int rc = 0;
+  if (e == hipSuccess) rc = set_state(m, tokens_host[0], start_pos, 1.0f, nullptr, 0);
+  const size_t V = (size_t)m->cfg.vocab_size;
+  for (int i = 0; rc == 0 && e == hipSuccess && i < num_tokens; ++i) {
+    set_token_kernel<<<1, 1, 0, m->stream>>>(m->state, toks_dev, i);
+    e = hipGraphLaunch(m->graph_exec, m->stream);
+    if (e == hipSuccess && all_logits_host)
+      e = hipMemcpyAsync(all_logits_host + (size_t)i * V, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream);
+  }
+  if (rc == 0 && e == hipSuccess && last_logits_host)
+    e = hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+  hipFree(toks_dev);
+  if (rc != 0) return rc;
+  TL_HIP(e);
+  return 0;
+}
+
+extern "C" int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out) {
+  TL_REQUIRE(m && m->finalized && dev_out, "tl_model_device_ptr: bad argument");
+  if (which == 2) {
+    *dev_out = m->x;
+    return 0;
+  }
+  TL_REQUIRE(layer >= 0 && layer < m->cfg.num_hidden_layers, "tl_model_device_ptr: layer %d out of range", layer);
+  TL_REQUIRE(which == 0 || which == 1, "tl_model_device_ptr: unknown buffer %d", which);
+  *dev_out = which == 0 ? m->kc(layer) : m->vc(layer);
+  return 0;
+}
+
+extern "C" int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, double* kv_bytes) {
+  TL_REQUIRE(m && m->finalized, "tl_model_bytes_per_token: model not finalized");
+  if (weight_bytes) *weight_bytes = m->weight_bytes;
+  if (kv_bytes)  // read K and V of positions 0..pos, write one position
+    *kv_bytes = (double)m->cfg.num_hidden_layers * 2.0 * ((double)pos + 2.0) * m->kv_dim * sizeof(float);
+  return 0;
+}
+
+extern "C" int tl_tp_unique_id(void* id_out_128) {
+  (void)id_out_128;
+  tl_set_error("tl_tp_unique_id: tensor parallelism is not wired up in this build");
+  return 3;
+}
+extern "C" int tl_model_tp_init(tl_model* m, const void* unique_id_128) {
+  (void)m;
+  (void)unique_id_128;
+  tl_set_error("tl_model_tp_init: tensor parallelism is not wired up in this build");
+  return 3;
+}
+
+// ---- operator-level batched mat-mul (prefill): Y[T][rows] = X[T][cols] W^T ----------------------------------
+// This build runs it as T GEMV launches over the quantized weights (each bit-identical to tl_matvec_q).
+extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream) {
+  TL_REQUIRE(w && x_dev && y_dev && num_tokens >= 0, "tl_matmul_q: bad argument");
+  for (int t = 0; t < num_tokens; ++t)
+    TL_TRY(tl_matvec_q(w, x_dev + (size_t)t * w->cols, y_dev + (size_t)t * w->rows, stream));
+  return 0;
+}

@@ -1,0 +1,233 @@
+"""Thin host-side objects over the C-ABI (capi.py): device buffers, quantized weights, the model engine.
+
+These mirror what the reference's host keeps as raw device-pointer members (model.h:498-554 weights and
+workspaces, model.h:135-143 KV) — here each is an owning Python object around a C-ABI handle. All compute
+happens in libtlhip.so; nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, lib
+
+_initialized = False
+
+
+def init(device=0):
+    global _initialized
+    check(lib().tl_init(device), "tl_init")
+    _initialized = True
+
+
+def _ensure_init():
+    if not _initialized:
+        init(0)
+
+
+class DeviceBuffer:
+    """A device allocation with numpy round trips (tl_malloc / tl_memcpy_*)."""
+
+    def __init__(self, nbytes):
+        _ensure_init()
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().tl_malloc(C.byref(p), self.nbytes), "tl_malloc")
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(max(a.nbytes, 4))
+        if a.nbytes:
+            check(lib().tl_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes, None), "tl_memcpy_h2d")
+        return b
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        if out.nbytes:
+            check(lib().tl_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes, None), "tl_memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().tl_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class QWeight:
+    """One quantized matrix resident in HBM (tl_qweight). `blocks`: raw GGUF blocks as a uint8 array."""
+
+    def __init__(self, typ, blocks, rows, cols):
+        _ensure_init()
+        blocks = np.ascontiguousarray(blocks)
+        h = C.c_void_p()
+        check(lib().tl_qweight_upload(typ, blocks.ctypes.data, rows, cols, C.byref(h), None), "tl_qweight_upload")
+        self.h, self.type, self.rows, self.cols = h.value, typ, rows, cols
+
+    def device_bytes(self):
+        n = C.c_size_t()
+        check(lib().tl_qweight_info(self.h, None, None, None, C.byref(n)), "tl_qweight_info")
+        return n.value
+
+    def dequantize(self, row0=0, nrows=None):
+        nrows = self.rows - row0 if nrows is None else nrows
+        out = DeviceBuffer(max(4, 4 * nrows * self.cols))
+        check(lib().tl_dequantize_rows(self.h, row0, nrows, out.ptr, None), "tl_dequantize_rows")
+        check(lib().tl_device_sync(), "sync")
+        return out.to_numpy(np.float32, (nrows, self.cols))
+
+    def matvec(self, x):
+        xb = DeviceBuffer.from_numpy(np.asarray(x, np.float32))
+        yb = DeviceBuffer(4 * self.rows)
+        check(lib().tl_matvec_q(self.h, xb.ptr, yb.ptr, None), "tl_matvec_q")
+        check(lib().tl_device_sync(), "sync")
+        return yb.to_numpy(np.float32, (self.rows,))
+
+    def free(self):
+        if self.h:
+            lib().tl_qweight_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+KINDS = {"attn_q": capi.T_ATTN_Q, "attn_k": capi.T_ATTN_K, "attn_v": capi.T_ATTN_V,
+         "attn_output": capi.T_ATTN_OUTPUT, "ffn_gate": capi.T_FFN_GATE, "ffn_up": capi.T_FFN_UP,
+         "ffn_down": capi.T_FFN_DOWN, "attn_norm": capi.T_ATTN_NORM, "ffn_norm": capi.T_FFN_NORM}
+
+
+def tensor_kind(name):
+    """GGUF tensor name (weight_management.cpp:732-960) -> (kind, layer)."""
+    if name == "token_embd.weight":
+        return capi.T_TOKEN_EMBD, -1
+    if name == "output_norm.weight":
+        return capi.T_OUTPUT_NORM, -1
+    if name == "output.weight":
+        return capi.T_OUTPUT, -1
+    _, li, kn, _ = name.split(".")
+    return KINDS[kn], int(li)
+
+
+class Model:
+    """The device-resident model (tl_model): cfg is a dict with the synth.SHAPES keys."""
+
+    def __init__(self, cfg, tp_rank=0, tp_size=1):
+        _ensure_init()
+        self.cfg = dict(cfg)
+        c = capi.ModelConfig(cfg["hidden"], cfg["inter"], cfg["n_heads"], cfg["n_kv_heads"], cfg["n_layers"],
+                             cfg["vocab"], cfg["max_pos"], cfg["eps"], cfg["rope_theta"], tp_rank, tp_size)
+        h = C.c_void_p()
+        check(lib().tl_model_create(C.byref(c), C.byref(h)), "tl_model_create")
+        self.h = h.value
+
+    def set_tensor(self, name, typ, arr, rows, cols):
+        kind, layer = tensor_kind(name)
+        arr = np.ascontiguousarray(arr)
+        check(lib().tl_model_set_tensor(self.h, kind, layer, typ, arr.ctypes.data, rows, cols),
+              f"tl_model_set_tensor({name})")
+
+    def load(self, tensors):
+        for name, (typ, arr, rows, cols) in tensors.items():
+            self.set_tensor(name, typ, arr, rows, cols)
+        self.finalize()
+        return self
+
+    def finalize(self):
+        check(lib().tl_model_finalize(self.h), "tl_model_finalize")
+
+    def reset_kv(self):
+        check(lib().tl_model_reset_kv(self.h), "tl_model_reset_kv")
+
+    def decode(self, token, pos, want_logits=True):
+        logits = np.empty(self.cfg["vocab"], np.float32) if want_logits else None
+        nxt = C.c_int(-1)
+        check(lib().tl_model_decode(self.h, int(token), int(pos), logits.ctypes.data if want_logits else None,
+                                    C.byref(nxt)), "tl_model_decode")
+        return logits, nxt.value
+
+    def generate_greedy(self, first_token, start_pos, n_steps, penalty=1.0, history=()):
+        hist = np.ascontiguousarray(history, np.int32)
+        out = np.zeros(max(n_steps, 1), np.int32)
+        check(lib().tl_model_generate_greedy(self.h, int(first_token), int(start_pos), int(n_steps), float(penalty),
+                                             hist.ctypes.data if hist.size else None, hist.size, out.ctypes.data),
+              "tl_model_generate_greedy")
+        return out[:n_steps]
+
+    def prefill(self, tokens, start_pos=0, all_logits=False):
+        toks = np.ascontiguousarray(tokens, np.int32)
+        last = np.empty(self.cfg["vocab"], np.float32)
+        allb = np.empty((toks.size, self.cfg["vocab"]), np.float32) if all_logits else None
+        check(lib().tl_model_prefill(self.h, toks.ctypes.data, toks.size, int(start_pos), last.ctypes.data,
+                                     allb.ctypes.data if all_logits else None), "tl_model_prefill")
+        return (last, allb) if all_logits else last
+
+    def generate(self, prompt, max_new, penalty=1.0, eos_id=-1):
+        """TinyLlamaSession::generate on token ids, greedy (api.cpp:585-813): prompts of >= 32
+        tokens go through tl_model_prefill, shorter ones are fed token by token; then device-side greedy steps."""
+        prompt = [int(t) for t in prompt]
+        P = len(prompt)
+        max_pos = self.cfg["max_pos"]
+        self.reset_kv()  # kv_cache_.clear_data(), api.cpp:592
+        if P >= 32:
+            logits = self.prefill(prompt, 0)
+        else:
+            for pos in range(P - 1):
+                if pos >= max_pos:
+                    return np.zeros(0, np.int32)
+                self.decode(prompt[pos], pos, want_logits=False)
+            if P - 1 >= max_pos:
+                return np.zeros(0, np.int32)
+            logits, _ = self.decode(prompt[P - 1], P - 1)
+        first = int(np.argmax(logits))  # empty history: the penalty is a no-op for the first sampled id
+        ids = [first]
+        # remaining steps on the device; the generate loop's bounds: pos < P + max_new - 1 and pos < max_pos
+        n_more = min(max_new - 1, max_pos - P)
+        if n_more > 0:  # an EOS sampled at pos == P-1 does not stop the loop (api.cpp:794)
+            more = self.generate_greedy(first, P, n_more, penalty, history=[first])
+            for t in more:
+                ids.append(int(t))
+                if int(t) == eos_id:
+                    break
+        return np.array(ids[:max_new], np.int32)
+
+    def device_ptr(self, which, layer=0):
+        p = C.c_void_p()
+        check(lib().tl_model_device_ptr(self.h, which, layer, C.byref(p)), "tl_model_device_ptr")
+        return p.value
+
+    def kv_cache(self, layer, n_pos):
+        kvd = self.cfg["n_kv_heads"] * (self.cfg["hidden"] // self.cfg["n_heads"])
+        out = []
+        for which in (0, 1):
+            a = np.empty((n_pos, kvd), np.float32)
+            check(lib().tl_memcpy_d2h(a.ctypes.data, self.device_ptr(which, layer), a.nbytes, None), "d2h")
+            out.append(a)
+        return out
+
+    def bytes_per_token(self, pos):
+        w, kv = C.c_double(), C.c_double()
+        check(lib().tl_model_bytes_per_token(self.h, int(pos), C.byref(w), C.byref(kv)), "tl_model_bytes_per_token")
+        return w.value, kv.value
+
+    def free(self):
+        if self.h:
+            lib().tl_model_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

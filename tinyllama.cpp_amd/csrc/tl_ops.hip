@@ -96,7 +96,10 @@ extern "C" int tl_rope_table_upload(float* table_dev, int max_pos, int head_dim,
 }
 
 // rotate pair i of head h of token t (utils.cpp:462-486); one thread per pair
+// (HIP's __fmul_rn is a plain multiply that hipcc may still contract into an FMA: contraction is switched off
+// for this function so that each product is rounded separately, as in the reference's x86-64 build.)
 __device__ __forceinline__ void rope_pair(float* xh, int i, int half, const float* tp, int adjacent) {
+#pragma clang fp contract(off)
   const float c = tp[2 * i], s = tp[2 * i + 1];
   const int i0 = adjacent ? 2 * i : i, i1 = adjacent ? 2 * i + 1 : i + half;
   const float a = xh[i0], b = xh[i1];

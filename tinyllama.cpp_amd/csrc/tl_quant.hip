@@ -234,7 +234,8 @@ extern "C" int tl_qweight_info(const tl_qweight* w, int* type, int* rows, int* c
 
 // ---------------------------------------------------------------------------------------------------
 // bit-exact dequantizer over the plane layout. Every float op is a separately rounded IEEE op in the
-// reference's order (__fmul_rn/__fsub_rn are never contracted into FMAs).
+// reference's order: FMA contraction is switched off inside the kernel (HIP's __fmul_rn alone does not
+// prevent hipcc from contracting a*b-c).
 // ---------------------------------------------------------------------------------------------------
 // quantization.cpp:47-90 restated with integer ops (v_cvt_f32_f16 is not used so that the result cannot
 // depend on the wave's f16 denormal mode)
@@ -260,6 +261,7 @@ __device__ inline float half_bits_to_float(uint32_t h, bool scale_field) {
 
 __global__ void dequant_rows_kernel(QW w, const int* __restrict__ row_index, int row0, int nrows,
                                     float* __restrict__ out) {
+#pragma clang fp contract(off)
   const int cpr = w.cols >> 5;  // chunks per row
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)nrows * cpr) return;

@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py — greedy decode throughput of the quantized forward pass on MI355X (BASELINE.json metric).
+
+A "step" is one decoded token: one pass of the hot path (embedding lookup, L transformer layers over the
+device-resident KV cache, lm_head, on-device greedy sampling) for one sequence. The default workload is the one
+the north star's target is quoted on and that fits one GPU: Llama-3-8B-shaped synthetic random-init Q4_K_M
+(SURVEY §8d tensor mix; 4.62 GB of quantized weights per token), weights resident in HBM before the timed region.
+
+    python bench.py --gpus 1 --steps 128 --warmup 16 [--workload llama-3-8b|tinyllama-1.1b|llama-3.2-3b|tiny]
+
+Prints ONE JSON line (rank 0). Timing: barrier + device sync on both sides, max over ranks. `roofline` is for the
+dominant kernel (the fused RMSNorm + gate/up GEMV + SwiGLU launch): algorithmic bytes per launch / its average
+duration measured with HIP events on the engine's stream. `cpu_baseline` times the CPU oracle (the reference's
+OpenMP CPU path restated, oracle/) on a bounded sample on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MIX = {"llama-3-8b": "q4_k_m", "tinyllama-1.1b": "q4_k_m", "llama-3.2-3b": "q6_k", "tiny": "q4_k_m",
+       "tiny-gqa": "q4_k_m"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default="llama-3-8b")
+    ap.add_argument("--mix", default=None)
+    ap.add_argument("--max-pos", type=int, default=2048, help="KV-cache length allocated for the run")
+    ap.add_argument("--prompt-len", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-layers", type=int, default=2, help="layers in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist = dist_mod
+    return rank, world, local, dist
+
+
+def main():
+    args = parse()
+    rank, world, local, dist = dist_setup(args.gpus)
+    from _pkg import load_package
+    pkg = load_package()
+    S = pkg.synth
+    from tinyllama_cpp_amd import engine
+    engine.init(local)
+
+    mix = args.mix or MIX.get(args.workload, "q4_k_m")
+    cfg = dict(S.SHAPES[args.workload])
+    cfg["max_pos"] = min(cfg["max_pos"], args.max_pos)
+    plan = S.tensor_plan(cfg, mix)
+
+    # ---- build + upload the synthetic model tensor by tensor (host copy dropped right away) ---------------
+    t_load = time.time()
+    model = engine.Model(cfg)
+    keep = {}  # host copies kept for the CPU-baseline sample: first layers + globals
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    for name, typ, rows, cols in plan:
+        arr = S.make_tensor(name, typ, rows, cols, seed=42)
+        model.set_tensor(name, typ, arr, rows, cols)
+        layer = int(name.split(".")[1]) if name.startswith("blk.") else -1
+        if want_cpu and (layer < 0 or layer < args.cpu_layers):
+            keep[name] = (typ, arr, rows, cols)
+        del arr
+    model.finalize()
+    t_load = time.time() - t_load
+
+    # ---- prompt (token by token: P < 32), then warm-up and the timed region --------------------------------
+    prompt = np.random.default_rng(0).integers(0, cfg["vocab"], args.prompt_len)
+    nxt = 0
+    for pos, tok in enumerate(prompt):
+        _, nxt = model.decode(int(tok), pos, want_logits=False)
+    pos = len(prompt)
+    if args.warmup > 0:
+        ids = model.generate_greedy(nxt, pos, args.warmup)
+        nxt, pos = int(ids[-1]), pos + args.warmup
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        engine.check(engine.lib().tl_device_sync(), "sync")
+
+    barrier()
+    t0 = time.perf_counter()
+    ids = model.generate_greedy(nxt, pos, args.steps)  # K graph replays back to back + one sync
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert len(ids) == args.steps and all(0 <= int(i) < cfg["vocab"] for i in ids)
+    mid_pos = pos + args.steps // 2
+    w_bytes, kv_bytes = model.bytes_per_token(mid_pos)
+    tok_s = args.steps / dt
+
+    # ---- per-kernel durations with HIP events (eager replays of the same step at the same positions) -------
+    prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
+    gu_ms, gu_n = prof["gate_up_gemv"]
+    H, I = cfg["hidden"], cfg["inter"]
+    gu_types = [t for n, t, r, c in plan if n.endswith("ffn_gate.weight") or n.endswith("ffn_up.weight")]
+    gu_bytes = sum(S.tensor_bytes(t, I, H) for t in gu_types) / max(1, len(gu_types) // 2)  # gate + up of one layer
+    gu_bytes += 4 * H * 2 + 4 * I  # x, norm weight, output
+    achieved = gu_bytes / (gu_ms * 1e-3) / 1e9 if gu_ms > 0 else 0.0
+
+    out = {
+        "metric": "decode tokens/sec + achieved HBM GB/s (% of peak) at Q4_K_M, 1/2/4/8 GPU",
+        "value": round(tok_s, 2),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic random-init weights (GGUF block formats), fixed token-id prompt",
+        "config": {"workload": f"{args.workload} {mix} greedy decode, batch 1, prompt {args.prompt_len}, "
+                               f"positions {pos}..{pos + args.steps - 1}, f32 KV cache",
+                   "parallelism": "single GPU" if world == 1 else f"replicas x{world}",
+                   "weight_bytes_per_token": int(w_bytes), "kv_bytes_per_token_mid": int(kv_bytes)},
+        "hbm_gbps_whole_step": round((w_bytes + kv_bytes) / (dt / args.steps) / 1e9, 1),
+        "hbm_frac_whole_step": round((w_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
+        "roofline": {"bound": "hbm", "kernel": "gemv_kernel<R, GEMV_GATE_UP> (RMSNorm + ffn_gate/ffn_up GEMV + SwiGLU)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "bytes_per_launch": int(gu_bytes), "avg_launch_us": round(gu_ms * 1e3, 2), "launches": gu_n},
+        "kernel_us": {k: round(v[0] * 1e3, 2) for k, v in prof.items()},
+        "load_s": round(t_load, 1),
+    }
+
+    # ---- CPU baseline: the oracle in the reference's structure on a bounded sample ------------------------------
+    if want_cpu:
+        out["cpu_baseline"] = cpu_baseline(cfg, keep, args.cpu_layers, w_bytes)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, keep, n_layers, w_bytes):
+    """Times tlo_forward in ref_structure mode (whole-tensor FP32 dequantization on first use, Kahan-double
+    mat-vec over OpenMP rows, eviction of layer l-2: what TinyLlamaModel::forward pays) for `n_layers` layers, once
+    cold and once warm, plus the lm_head mat-vec, and scales to the full depth: (L-2) cold + 2 warm layers + tail."""
+    from oracle.oracle import Oracle, OracleModel
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+    o = Oracle()
+    sub = dict(cfg, n_layers=n_layers, max_pos=16)
+    om = OracleModel(o, sub, keep)
+    om.set_ref_structure(True)
+    x = om.lookup_embedding(1)
+    t0 = time.perf_counter()
+    om.forward(x, 0, n_layers_limit=n_layers, want_logits=False)  # cold: every tensor dequantized, as for the
+    t_cold = (time.perf_counter() - t0) / n_layers                # L-2 layers evicted since the previous token
+    t0 = time.perf_counter()
+    om.forward(x, 1, n_layers_limit=n_layers, want_logits=False)  # warm: the last two layers keep their FP32 copy
+    t_warm = (time.perf_counter() - t0) / n_layers
+    om.forward(x, 2)  # first logits call dequantizes lm_head once (kept, weight_management.cpp:10-42)
+    t0 = time.perf_counter()
+    om.forward(x, 3)
+    t_tail = max(time.perf_counter() - t0 - t_warm * n_layers, 0.0)  # final norm + lm_head mat-vec
+    L = cfg["n_layers"]
+    t_tok = t_cold * max(L - 2, 0) + t_warm * min(L, 2) + t_tail
+    om.close()
+    return {"value": round(1.0 / t_tok, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{n_layers} of {cfg['n_layers']} layers x 2 tokens + lm_head, scaled to full depth; "
+                      "reference structure (per-token whole-tensor dequant, Kahan-double mat-vec, l-2 eviction)",
+            "s_per_token": round(t_tok, 3), "gbps": round(w_bytes / t_tok / 1e9, 3)}
+
+
+if __name__ == "__main__":
+    main()

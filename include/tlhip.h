@@ -150,6 +150,12 @@ int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_
  * last_logits_host[vocab] (may be NULL) = logits of the last token; all_logits_host[T][vocab] may be NULL */
 int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
                      float* all_logits_host);
+/* Measurement hook (no counterpart in the reference): runs n_steps greedy decode steps EAGERLY (no graph) on the
+ * model's stream with a HIP event after every kernel, and accumulates per-kernel-kind milliseconds and launch
+ * counts into kind_ms_out[9] / kind_launches_out[9]: 0 embed, 1 norm+QKV GEMV, 2 RoPE+KV write, 3 attention,
+ * 4 O GEMV+residual, 5 norm+gate/up GEMV+SwiGLU, 6 down GEMV+residual, 7 norm+lm_head GEMV, 8 sample+advance. */
+int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_steps, float* kind_ms_out,
+                            int* kind_launches_out);
 /* device pointers into the model's state, for parity tests and for hosts that keep using the operator-level
  * calls: which = 0 K cache, 1 V cache of `layer` ([max_pos][n_kv_heads_local][head_dim] f32), 2 = x (hidden) */
 int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out);

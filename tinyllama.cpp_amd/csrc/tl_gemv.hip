@@ -256,7 +256,8 @@ __device__ __forceinline__ void stage_x(const GemvArgs& a, float* smem) {
   __syncthreads();
 }
 
-template <int R>
+// ROLE only names the instantiation (tl_internal.h GemvRole) so that profiles separate the per-layer launches.
+template <int R, int ROLE>
 __global__ __launch_bounds__(GEMV_THREADS) void gemv_kernel(GemvArgs a, int t0, int t1, int t2) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   stage_x(a, smem);
@@ -306,12 +307,32 @@ static int g_gemv_attr_done = 0;
 static int g_gemv_R_override = -1;
 static int g_num_cus = 256;
 
+template <int R, int ROLE>
+static int gemv_launch_one(const GemvArgs& a, int grid, size_t lds, const int* t, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<R, ROLE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  gemv_kernel<R, ROLE><<<grid, GEMV_THREADS, lds, s>>>(a, t[0], t[1], t[2]);
+  return 0;
+}
+
+template <int R>
+static int gemv_launch_role(const GemvArgs& a, int grid, size_t lds, const int* t, hipStream_t s) {
+  switch (a.role) {
+    case GEMV_QKV: return gemv_launch_one<R, GEMV_QKV>(a, grid, lds, t, s);
+    case GEMV_ATTN_OUT: return gemv_launch_one<R, GEMV_ATTN_OUT>(a, grid, lds, t, s);
+    case GEMV_GATE_UP: return gemv_launch_one<R, GEMV_GATE_UP>(a, grid, lds, t, s);
+    case GEMV_DOWN: return gemv_launch_one<R, GEMV_DOWN>(a, grid, lds, t, s);
+    case GEMV_LM_HEAD: return gemv_launch_one<R, GEMV_LM_HEAD>(a, grid, lds, t, s);
+    default: return gemv_launch_one<R, GEMV_GENERIC>(a, grid, lds, t, s);
+  }
+}
+
 static int gemv_setup() {
   if (g_gemv_attr_done) return 0;
-  const int max_lds = 160 * 1024;
-  TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-  TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
-  TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, max_lds));
   int dev = 0;
   TL_HIP(hipGetDevice(&dev));
   hipDeviceProp_t prop;
@@ -355,9 +376,9 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   const int cap = g_num_cus * blocks_per_cu;
   if (grid > cap) grid = cap;
   switch (R) {
-    case 1: gemv_kernel<1><<<grid, GEMV_THREADS, lds, s>>>(a, t[0], t[1], t[2]); break;
-    case 2: gemv_kernel<2><<<grid, GEMV_THREADS, lds, s>>>(a, t[0], t[1], t[2]); break;
-    default: gemv_kernel<4><<<grid, GEMV_THREADS, lds, s>>>(a, t[0], t[1], t[2]); break;
+    case 1: TL_TRY((gemv_launch_role<1>(a, grid, lds, t, s))); break;
+    case 2: TL_TRY((gemv_launch_role<2>(a, grid, lds, t, s))); break;
+    default: TL_TRY((gemv_launch_role<4>(a, grid, lds, t, s))); break;
   }
   TL_HIP(hipGetLastError());
   return 0;

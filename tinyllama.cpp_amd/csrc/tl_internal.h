@@ -70,6 +70,7 @@ int tl_qweight_build(int type, const void* host_blocks, int rows, int cols, tl_q
 // ---- launchers shared between the operator-level C-ABI and the model engine ---------------------------
 // GEMV over 1..3 matrices that share the input vector (q|k|v in one launch), with optional fused
 // RMSNorm prologue, residual epilogue, or gate/up SwiGLU pairing; see tl_gemv.hip
+enum GemvRole { GEMV_GENERIC = 0, GEMV_QKV, GEMV_ATTN_OUT, GEMV_GATE_UP, GEMV_DOWN, GEMV_LM_HEAD };
 struct GemvSeg {
   QW w;
   float* out;
@@ -83,6 +84,7 @@ struct GemvArgs {
   const float* norm_w;  // != NULL: x := rmsnorm_vector(x, norm_w, eps) first (utils.cpp:648-673)
   float eps;
   const float* resid;   // != NULL: out0[r] = resid[r] + y[r]   (single segment only)
+  int role;             // GemvRole: selects a separately named instantiation (profiling only)
 };
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
 

@@ -225,13 +225,31 @@ __global__ __launch_bounds__(1024) void sample_advance_kernel(float* __restrict_
   }
 }
 
-static int enqueue_step(tl_model* m) {
+// Optional per-kernel timing: when `prof` is set, an event is recorded before the first launch and after every
+// launch of the step (kinds in tl_model_profile_decode's order).
+struct StepProf {
+  std::vector<hipEvent_t> ev;
+  std::vector<int> kind;
+  int mark(hipStream_t s, int k) {
+    hipEvent_t e;
+    TL_HIP(hipEventCreate(&e));
+    TL_HIP(hipEventRecord(e, s));
+    ev.push_back(e);
+    kind.push_back(k);
+    return 0;
+  }
+};
+#define PROF_MARK(k) do { if (prof) TL_TRY(prof->mark(s, (k))); } while (0)
+
+static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
   const tl_model_config& c = m->cfg;
   hipStream_t s = m->stream;
   const int* tok_dev = m->state;
   const int* pos_dev = m->state + 1;
   const float scale = 1.0f / sqrtf((float)m->head_dim);
+  PROF_MARK(-1);
   TL_TRY(tl_launch_dequant_rows(m->tok, tok_dev, 0, 1, m->x, s));
+  PROF_MARK(0);
   for (int l = 0; l < c.num_hidden_layers; ++l) {
     LayerW& L = m->layers[l];
     GemvArgs a = {};
@@ -243,18 +261,24 @@ static int enqueue_step(tl_model* m) {
     a.x = m->x;
     a.norm_w = L.attn_norm;
     a.eps = c.rms_norm_eps;
+    a.role = GEMV_QKV;
     TL_TRY(tl_launch_gemv(a, s));
+    PROF_MARK(1);
     TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, c.num_attention_heads,
                              c.num_key_value_heads, m->head_dim, pos_dev, c.max_position_embeddings, s));
+    PROF_MARK(2);
     TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, c.num_attention_heads, c.num_key_value_heads,
                                  m->head_dim, 0, pos_dev, c.max_position_embeddings, scale, s));
+    PROF_MARK(3);
     GemvArgs o = {};
     o.seg[0] = {qw_view(L.q[TL_T_ATTN_OUTPUT]), m->x};
     o.nseg = 1;
     o.cols = c.hidden_size;
     o.x = m->att;
     o.resid = m->x;
+    o.role = GEMV_ATTN_OUT;
     TL_TRY(tl_launch_gemv(o, s));
+    PROF_MARK(4);
     GemvArgs g = {};
     g.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), m->h};
     g.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), nullptr};
@@ -264,14 +288,18 @@ static int enqueue_step(tl_model* m) {
     g.x = m->x;
     g.norm_w = L.ffn_norm;
     g.eps = c.rms_norm_eps;
+    g.role = GEMV_GATE_UP;
     TL_TRY(tl_launch_gemv(g, s));
+    PROF_MARK(5);
     GemvArgs d = {};
     d.seg[0] = {qw_view(L.q[TL_T_FFN_DOWN]), m->x};
     d.nseg = 1;
     d.cols = c.intermediate_size;
     d.x = m->h;
     d.resid = m->x;
+    d.role = GEMV_DOWN;
     TL_TRY(tl_launch_gemv(d, s));
+    PROF_MARK(6);
   }
   GemvArgs f = {};
   f.seg[0] = {qw_view(m->out), m->logits};
@@ -280,9 +308,12 @@ static int enqueue_step(tl_model* m) {
   f.x = m->x;
   f.norm_w = m->out_norm;
   f.eps = c.rms_norm_eps;
+  f.role = GEMV_LM_HEAD;
   TL_TRY(tl_launch_gemv(f, s));
+  PROF_MARK(7);
   sample_advance_kernel<<<1, 1024, 0, s>>>(m->logits, c.vocab_size, m->state, m->hist_cap);
   TL_HIP(hipGetLastError());
+  PROF_MARK(8);
   return 0;
 }
 
@@ -416,6 +447,36 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   hipFree(toks_dev);
   if (rc != 0) return rc;
   TL_HIP(e);
+  return 0;
+}
+
+extern "C" int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_steps, float* kind_ms_out,
+                                       int* kind_launches_out) {
+  TL_REQUIRE(m && m->finalized && kind_ms_out && kind_launches_out, "tl_model_profile_decode: bad argument");
+  TL_REQUIRE(n_steps > 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
+             "tl_model_profile_decode: positions out of range");
+  for (int k = 0; k < 9; ++k) {
+    kind_ms_out[k] = 0.f;
+    kind_launches_out[k] = 0;
+  }
+  TL_TRY(set_state(m, first_token, start_pos, 1.0f, nullptr, 0));
+  for (int i = 0; i < n_steps; ++i) {
+    StepProf prof;
+    int rc = enqueue_step(m, &prof);
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (rc == 0 && e == hipSuccess) {
+      for (size_t j = 1; j < prof.ev.size(); ++j) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, prof.ev[j - 1], prof.ev[j]) == hipSuccess) {
+          kind_ms_out[prof.kind[j]] += ms;
+          kind_launches_out[prof.kind[j]] += 1;
+        }
+      }
+    }
+    for (hipEvent_t ev : prof.ev) hipEventDestroy(ev);
+    if (rc != 0) return rc;
+    TL_HIP(e);
+  }
   return 0;
 }
 

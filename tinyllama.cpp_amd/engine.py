@@ -202,6 +202,17 @@ class Model:
                     break
         return np.array(ids[:max_new], np.int32)
 
+    PROFILE_KINDS = ("embed", "qkv_gemv", "rope_kv", "attention", "attn_out_gemv", "gate_up_gemv", "down_gemv",
+                     "lm_head_gemv", "sample")
+
+    def profile_decode(self, first_token, start_pos, n_steps):
+        """{kind: (avg_ms_per_launch, launches)} from HIP events around every kernel of eager decode steps."""
+        ms = np.zeros(9, np.float32)
+        cnt = np.zeros(9, np.int32)
+        check(lib().tl_model_profile_decode(self.h, int(first_token), int(start_pos), int(n_steps), ms.ctypes.data,
+                                            cnt.ctypes.data), "tl_model_profile_decode")
+        return {k: (float(ms[i]) / max(int(cnt[i]), 1), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+
     def device_ptr(self, which, layer=0):
         p = C.c_void_p()
         check(lib().tl_model_device_ptr(self.h, which, layer, C.byref(p)), "tl_model_device_ptr")

@@ -150,6 +150,10 @@ int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_
  * last_logits_host[vocab] (may be NULL) = logits of the last token; all_logits_host[T][vocab] may be NULL */
 int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
                      float* all_logits_host);
+/* Measurement hook (no counterpart in the reference): `iters` back-to-back tl_matvec_q launches cycling through
+ * `nw` equally-shaped matrices (use more than the 256 MiB Infinity Cache holds), timed with HIP events on `stream`. */
+int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int iters, int warmup,
+                    float* avg_us_out, void* stream);
 /* Measurement hook (no counterpart in the reference): runs n_steps greedy decode steps EAGERLY (no graph) on the
  * model's stream with a HIP event after every kernel, and accumulates per-kernel-kind milliseconds and launch
  * counts into kind_ms_out[9] / kind_launches_out[9]: 0 embed, 1 norm+QKV GEMV, 2 RoPE+KV write, 3 attention,

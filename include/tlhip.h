@@ -154,6 +154,10 @@ int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int st
  * `nw` equally-shaped matrices (use more than the 256 MiB Infinity Cache holds), timed with HIP events on `stream`. */
 int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int iters, int warmup,
                     float* avg_us_out, void* stream);
+/* Diagnostic hook (no counterpart in the reference): one tl_matvec_q-shaped launch of an instrumented build of the
+ * GEMV kernel; stamps_dev[8 * grid * waves] u64 receives per-wave shader-clock stamps (see tl_gemv.hip). */
+int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, unsigned long long* stamps_dev,
+                         int* grid_out, int* waves_out, void* stream);
 /* Measurement hook (no counterpart in the reference): runs n_steps greedy decode steps EAGERLY (no graph) on the
  * model's stream with a HIP event after every kernel, and accumulates per-kernel-kind milliseconds and launch
  * counts into kind_ms_out[9] / kind_launches_out[9]: 0 embed, 1 norm+QKV GEMV, 2 RoPE+KV write, 3 attention,

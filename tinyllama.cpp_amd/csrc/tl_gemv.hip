@@ -15,6 +15,9 @@
 //   - a wave's step is TWO weight streams x one span sharing the same x chunk: two consecutive rows, or the same
 //     row of ffn_gate and ffn_up. Steps are register double-buffered: the loads of step i+1 are issued before step i
 //     is consumed, and a wave's first loads go out before x is staged, so the HBM round trip overlaps the prologue;
+//   - the block format is a COMPILE-TIME parameter of a wave's loop (a type switch inside the loop makes the compiler
+//     wait for every load right where it is issued). A launch may mix two formats (attn_q/attn_k Q4_K + attn_v Q6_K in
+//     the Q4_K_M mix): the waves of a workgroup are split between the two classes in proportion to their bytes;
 //   - row groups are dealt round-robin over all waves of the chip (consecutive groups on different CUs);
 //   - weights are loaded non-temporal (each byte is read once per token);
 //   - nibble/byte unpack is v_and/v_lshr + v_cvt_f32_ubyteN, FP32 FMA chains, DPP wave reduction;
@@ -30,6 +33,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int XS_STRIDE = 36;   // floats per staged chunk: 32 x + sum(x[0..15]) + sum(x[16..31]) + 2 pad
 constexpr int XS_SCRATCH = 64;  // floats reserved at the start of dynamic LDS for block reductions
 constexpr int GEMV_MAX_THREADS = 1024;
+constexpr int TL_NONE = -1;     // "no second format class" marker for the kernel template
 
 // ---- wave reduction with DPP (no LDS traffic): the total lands in lane 63 --------------------------------
 template <int CTRL, int ROW_MASK>
@@ -75,115 +79,114 @@ __device__ __forceinline__ float dot4(unsigned v, const float* x, float acc) {
   return acc;
 }
 
-// ---- one 32-weight chunk in registers, format-agnostic container (9 VGPRs) ---------------------------------
-//   Q4_K: a = payload, b = super-block header          Q6_K: a = ql', b = {qh'.x, qh'.y, sc pair, d}
-//   Q8_0/Q8_K: a,b = 32 payload bytes, c = d           F32 is handled by a separate (cold) path
-struct Raw {
-  u32x4 a, b;
-  unsigned c;
-};
-
-// one weight stream of a step: a matrix and a (wave-uniform) row of it
-struct Stream {
-  QW w;
-  int row;
-};
-
-template <bool NT, typename T>
+// Non-temporal load through an explicitly GLOBAL pointer: the segment pointers pass through integer arithmetic
+// (group_of), after which the compiler no longer knows their address space and would emit flat_load, whose
+// completion is unordered and forces vmcnt(0) waits.
+template <typename T>
 __device__ __forceinline__ T ldg(const uint8_t* base, unsigned byte_off) {
-  const T* p = reinterpret_cast<const T*>(base + byte_off);
-  return NT ? __builtin_nontemporal_load(p) : *p;
+  typedef const T __attribute__((address_space(1))) * gptr;
+  return __builtin_nontemporal_load((gptr)(unsigned long long)(base + byte_off));
+}
+__device__ __forceinline__ float ldg_f32(const float* p) {
+  typedef const float __attribute__((address_space(1))) * gptr;
+  return *(gptr)(unsigned long long)p;
+}
+__device__ __forceinline__ void stg_f32(float* p, float v) {
+  typedef float __attribute__((address_space(1))) * gptr;
+  *(gptr)(unsigned long long)p = v;
 }
 
-// chunk c of the stream's row; all base addresses are wave-uniform, the per-lane part is a 32-bit byte offset
-template <bool NT>
-__device__ __forceinline__ void chunk_load(const Stream& s, unsigned c, Raw& r) {
-  const size_t row = (size_t)s.row;
-  const size_t cols = (size_t)s.w.cols;
-  switch (s.w.type) {  // wave-uniform
-    case TL_Q4_K:
-      r.a = ldg<NT, u32x4>(s.w.p0 + row * (cols >> 1), c * 16u);
-      r.b = ldg<NT, u32x4>(s.w.p1 + row * (cols >> 4), (c >> 3) * 16u);
-      break;
-    case TL_Q6_K: {
-      r.a = ldg<NT, u32x4>(s.w.p0 + row * (cols >> 1), c * 16u);
-      const u32x2 h = ldg<NT, u32x2>(s.w.p1 + row * (cols >> 2), c * 8u);
-      r.b[0] = h[0];
-      r.b[1] = h[1];
-      r.b[2] = ldg<NT, unsigned short>(s.w.p2 + row * (cols >> 4), c * 2u);
-      r.b[3] = ldg<NT, unsigned short>(s.w.p3 + row * (cols >> 7), (c >> 3) * 2u);
-      break;
-    }
-    case TL_Q8_0:
-      r.a = ldg<NT, u32x4>(s.w.p0 + row * cols, c * 32u);
-      r.b = ldg<NT, u32x4>(s.w.p0 + row * cols, c * 32u + 16u);
-      r.c = ldg<NT, unsigned short>(s.w.p1 + row * (cols >> 4), c * 2u);
-      break;
-    case TL_Q8_K:
-      r.a = ldg<NT, u32x4>(s.w.p0 + row * cols, c * 32u);
-      r.b = ldg<NT, u32x4>(s.w.p0 + row * cols, c * 32u + 16u);
-      r.c = ldg<NT, unsigned short>(s.w.p1 + row * (cols >> 7), (c >> 3) * 2u);
-      break;
-    default: break;
-  }
-}
+// ---- per-format: one 32-weight chunk in registers, its loads and its dot with 32 x ----------------------------
+// `base*` arguments are wave-uniform row bases, the per-lane part is a 32-bit byte offset
+template <int TYPE>
+struct Chunk;
 
 // (d*sc) * sum(q*x) - (dmin*m) * sum(x)  ==  sum((d*sc*q - dmin*m) * x)   (quantization.cpp:200-215)
-__device__ __forceinline__ float dot_q4k(const Raw& r, const float* x, float s0, float s1, int j) {
-  float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    const unsigned lo = r.a[w] & 0x0F0F0F0Fu, hi = (r.a[w] >> 4) & 0x0F0F0F0Fu;
-    a0 = dot4(lo, x + 8 * w, a0);
-    a1 = dot4(hi, x + 8 * w + 4, a1);
+template <>
+struct Chunk<TL_Q4_K> {
+  u32x4 a, b;  // payload, super-block header
+  __device__ __forceinline__ void load(const QW& w, int row, unsigned c) {
+    const size_t r = (size_t)row, cols = (size_t)w.cols;
+    a = ldg<u32x4>(w.p0 + r * (cols >> 1), c * 16u);
+    b = ldg<u32x4>(w.p1 + r * (cols >> 4), (c >> 3) * 16u);
   }
-  const float d = half_to_float(r.b[0] & 0xffffu), dmin = half_to_float(r.b[0] >> 16);
-  const unsigned sc = ((r.b[1] >> (4 * j)) & 15u) | (((r.b[3] >> (2 * j)) & 3u) << 4);
-  const unsigned mn = ((r.b[2] >> (4 * j)) & 15u) | (((r.b[3] >> (16 + 2 * j)) & 3u) << 4);
-  return (d * (float)sc) * (a0 + a1) - (dmin * (float)mn) * (s0 + s1);
-}
+  __device__ __forceinline__ float dot(const float* x, float s0, float s1, int j) const {
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const unsigned lo = a[w] & 0x0F0F0F0Fu, hi = (a[w] >> 4) & 0x0F0F0F0Fu;
+      a0 = dot4(lo, x + 8 * w, a0);
+      a1 = dot4(hi, x + 8 * w + 4, a1);
+    }
+    const float d = half_to_float(b[0] & 0xffffu), dmin = half_to_float(b[0] >> 16);
+    const unsigned sc = ((b[1] >> (4 * j)) & 15u) | (((b[3] >> (2 * j)) & 3u) << 4);
+    const unsigned mn = ((b[2] >> (4 * j)) & 15u) | (((b[3] >> (16 + 2 * j)) & 3u) << 4);
+    return (d * (float)sc) * (a0 + a1) - (dmin * (float)mn) * (s0 + s1);
+  }
+};
 
 // d*sc*(q6-32) summed per 16-weight sub-block (quantization.cpp:255-263)
-__device__ __forceinline__ float dot_q6k(const Raw& r, const float* x, float s0, float s1) {
-  float acc[2];
-#pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const unsigned h = r.b[v];
-    const unsigned l0 = r.a[2 * v], l1 = r.a[2 * v + 1];
-    const unsigned c0 = (l0 & 0x0F0F0F0Fu) | ((h << 4) & 0x30303030u);
-    const unsigned c1 = ((l0 >> 4) & 0x0F0F0F0Fu) | ((h << 2) & 0x30303030u);
-    const unsigned c2 = (l1 & 0x0F0F0F0Fu) | (h & 0x30303030u);
-    const unsigned c3 = ((l1 >> 4) & 0x0F0F0F0Fu) | ((h >> 2) & 0x30303030u);
-    float a = 0.f, b = 0.f;
-    a = dot4(c0, x + 16 * v, a);
-    b = dot4(c1, x + 16 * v + 4, b);
-    a = dot4(c2, x + 16 * v + 8, a);
-    b = dot4(c3, x + 16 * v + 12, b);
-    acc[v] = a + b;
+template <>
+struct Chunk<TL_Q6_K> {
+  u32x4 a;  // ql'
+  u32x2 h;  // qh'
+  unsigned sc, d;
+  __device__ __forceinline__ void load(const QW& w, int row, unsigned c) {
+    const size_t r = (size_t)row, cols = (size_t)w.cols;
+    a = ldg<u32x4>(w.p0 + r * (cols >> 1), c * 16u);
+    h = ldg<u32x2>(w.p1 + r * (cols >> 2), c * 8u);
+    sc = ldg<unsigned short>(w.p2 + r * (cols >> 4), c * 2u);
+    d = ldg<unsigned short>(w.p3 + r * (cols >> 7), (c >> 3) * 2u);
   }
-  const float d = half_to_float(r.b[3]);
-  const float sc0 = (float)(int)(signed char)(r.b[2] & 0xffu), sc1 = (float)(int)(signed char)((r.b[2] >> 8) & 0xffu);
-  return (d * sc0) * (acc[0] - 32.0f * s0) + (d * sc1) * (acc[1] - 32.0f * s1);
-}
+  __device__ __forceinline__ float dot(const float* x, float s0, float s1, int) const {
+    float acc[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const unsigned hh = h[v];
+      const unsigned l0 = a[2 * v], l1 = a[2 * v + 1];
+      const unsigned c0 = (l0 & 0x0F0F0F0Fu) | ((hh << 4) & 0x30303030u);
+      const unsigned c1 = ((l0 >> 4) & 0x0F0F0F0Fu) | ((hh << 2) & 0x30303030u);
+      const unsigned c2 = (l1 & 0x0F0F0F0Fu) | (hh & 0x30303030u);
+      const unsigned c3 = ((l1 >> 4) & 0x0F0F0F0Fu) | ((hh >> 2) & 0x30303030u);
+      float p = 0.f, q = 0.f;
+      p = dot4(c0, x + 16 * v, p);
+      q = dot4(c1, x + 16 * v + 4, q);
+      p = dot4(c2, x + 16 * v + 8, p);
+      q = dot4(c3, x + 16 * v + 12, q);
+      acc[v] = p + q;
+    }
+    const float df = half_to_float(d);
+    const float sc0 = (float)(int)(signed char)(sc & 0xffu), sc1 = (float)(int)(signed char)((sc >> 8) & 0xffu);
+    return (df * sc0) * (acc[0] - 32.0f * s0) + (df * sc1) * (acc[1] - 32.0f * s1);
+  }
+};
 
 // |d| * sum(q*x): bytes are biased by +128 for the unsigned byte->float convert, folded back with sum(x)
-__device__ __forceinline__ float dot_q8(const Raw& r, const float* x, float s0, float s1) {
-  float a0 = 0.f, a1 = 0.f;
+template <int TYPE>
+struct ChunkQ8 {
+  u32x4 a, b;
+  unsigned d;
+  __device__ __forceinline__ void load(const QW& w, int row, unsigned c) {
+    const size_t r = (size_t)row, cols = (size_t)w.cols;
+    a = ldg<u32x4>(w.p0 + r * cols, c * 32u);
+    b = ldg<u32x4>(w.p0 + r * cols, c * 32u + 16u);
+    d = TYPE == TL_Q8_0 ? ldg<unsigned short>(w.p1 + r * (cols >> 4), c * 2u)
+                        : ldg<unsigned short>(w.p1 + r * (cols >> 7), (c >> 3) * 2u);
+  }
+  __device__ __forceinline__ float dot(const float* x, float s0, float s1, int) const {
+    float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    a0 = dot4(r.a[w] ^ 0x80808080u, x + 4 * w, a0);
-    a1 = dot4(r.b[w] ^ 0x80808080u, x + 16 + 4 * w, a1);
+    for (int w = 0; w < 4; ++w) {
+      a0 = dot4(a[w] ^ 0x80808080u, x + 4 * w, a0);
+      a1 = dot4(b[w] ^ 0x80808080u, x + 16 + 4 * w, a1);
+    }
+    return scale_field(d) * ((a0 + a1) - 128.0f * (s0 + s1));
   }
-  return scale_field(r.c) * ((a0 + a1) - 128.0f * (s0 + s1));
-}
-
-__device__ __forceinline__ float chunk_dot(int type, const Raw& r, const float* x, float s0, float s1, int j) {
-  switch (type) {  // wave-uniform
-    case TL_Q4_K: return dot_q4k(r, x, s0, s1, j);
-    case TL_Q6_K: return dot_q6k(r, x, s0, s1);
-    default: return dot_q8(r, x, s0, s1);
-  }
-}
+};
+template <>
+struct Chunk<TL_Q8_0> : ChunkQ8<TL_Q8_0> {};
+template <>
+struct Chunk<TL_Q8_K> : ChunkQ8<TL_Q8_K> {};
 
 // the vector-side arguments of a launch (the segments travel as separate kernel parameters)
 struct GemvVec {
@@ -192,28 +195,46 @@ struct GemvVec {
   const float* resid;
   float eps;
   int cols;
+  unsigned long long* stamps;  // diagnostic instantiation only: 8 shader-clock stamps per wave
 };
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
-__device__ __forceinline__ void stage_x(const GemvVec a, float* smem) {
+// Split in two so that the x loads are the FIRST loads a wave issues: loads return in order, and staging must not
+// wait behind the first weight loads (an HBM round trip) that are issued in between.
+struct XRegs {
+  f32x4 v[4];  // the first four float4 of a thread (covers cols <= 16 * blockDim)
+  f32x4 g[2];  // norm weights of the first two (norm launches have cols = hidden_size <= 8 * blockDim in practice)
+};
+// Unconditional (index-clamped) loads: a load under a branch makes the compiler wait with vmcnt(0) at the join,
+// which would also wait for the weight loads issued after these.
+__device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
+  const int n4 = a.cols >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    r.v[k] = x4[i < n4 ? i : n4 - 1];
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int i = threadIdx.x + k * blockDim.x;
+    r.g[k] = w4[i < n4 ? i : n4 - 1];
+  }
+}
+__device__ __forceinline__ float ssq4(f32x4 t) { return (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]); }
+__device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r, float* smem) {
   float* xs = smem + XS_SCRATCH;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int n4 = a.cols >> 2;
   const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
   const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w);
-  // the first two float4 of a thread stay in registers across the reduction (covers cols <= 8 * blockDim)
-  const int i0 = tid, i1 = tid + nthr;
-  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-  if (i0 < n4) v0 = x4[i0];
-  if (i1 < n4) v1 = x4[i1];
   float nf = 1.0f;
   if (a.norm_w) {
-    float ssq = (v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3]);
-    ssq += (v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]);
-    for (int i = tid + 2 * nthr; i < n4; i += nthr) {
-      const f32x4 t = x4[i];
-      ssq += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
-    }
+    float ssq = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ssq += (tid + k * nthr < n4) ? ssq4(r.v[k]) : 0.f;
+    for (int i = tid + 4 * nthr; i < n4; i += nthr) ssq += ssq4(x4[i]);
     ssq = wave_sum_all(ssq);
     if ((tid & 63) == 0) smem[tid >> 6] = ssq;
     __syncthreads();
@@ -222,9 +243,8 @@ __device__ __forceinline__ void stage_x(const GemvVec a, float* smem) {
     const float e = a.eps < 1e-5f ? 1e-5f : a.eps;  // SAFE_MAX(eps, MIN_NORM_EPS)
     nf = 1.0f / sqrtf(tot / (float)a.cols + e);
   }
-  auto put = [&](int i, f32x4 t) {
+  auto put = [&](int i, f32x4 t, f32x4 g) {
     if (a.norm_w) {
-      const f32x4 g = w4[i];
       t[0] = t[0] * nf * g[0]; t[1] = t[1] * nf * g[1]; t[2] = t[2] * nf * g[2]; t[3] = t[3] * nf * g[3];
     }
     const int idx = i << 2;
@@ -237,34 +257,30 @@ __device__ __forceinline__ void stage_x(const GemvVec a, float* smem) {
     if ((i & 3) == 0) dst[32 + ((i >> 2) & 1)] = s;
   };
   // n4 is a multiple of 8 and blockDim of 64, so quads of threads are all-in or all-out of every branch
-  if (i0 < n4) put(i0, v0);
-  if (i1 < n4) put(i1, v1);
-  for (int i = tid + 2 * nthr; i < n4; i += nthr) put(i, x4[i]);
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = tid + k * nthr;
+    if (i < n4) put(i, r.v[k], k < 2 ? r.g[k] : (a.norm_w ? w4[i] : one));
+  }
+  for (int i = tid + 4 * nthr; i < n4; i += nthr) put(i, x4[i], a.norm_w ? w4[i] : one);
   __syncthreads();
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------
-struct Step {
-  Raw r0, r1;
-};
-
-// the segments of a launch as plain scalars (no array: a dynamically indexed by-value kernel argument is copied to
-// scratch and drags every address computation into VGPRs)
+// The segments of one format class as plain scalars (no array: a dynamically indexed by-value kernel argument is
+// copied to scratch and drags every address computation into VGPRs).
 struct Segs {
   QW w0, w1, w2;
   float *o0, *o1, *o2;
-  const float* resid;
-  int t0, t1;
+  int t0, t1;  // row groups in segments 0 and 1
 };
 
-// the two streams of row group `rg`: rows (2*lt, 2*lt+1) of one segment, or row lt of the gate/up pair
+// row group `rg` of a class: rows (2*lt, 2*lt+1) of one of its segments, or row lt of the gate/up pair
 template <bool PAIR>
-__device__ __forceinline__ void streams_of(const Segs& g, int rg, Stream& s0, Stream& s1, float*& out, int& row0) {
-  if (PAIR) {
-    s0.w = g.w0;
-    s1.w = g.w1;
-    s0.row = s1.row = row0 = rg;
-    out = g.o0;
+__device__ __forceinline__ void group_of(const Segs& g, int rg, QW& wa, QW& wb, int& ra, int& rb, float*& out) {
+  if (PAIR) {  // wa / wb / out were set once by the caller and never change
+    ra = rb = rg;
     return;
   }
   int seg = 0, lt = rg;
@@ -276,122 +292,168 @@ __device__ __forceinline__ void streams_of(const Segs& g, int rg, Stream& s0, St
     return reinterpret_cast<const uint8_t*>(((unsigned long long)x0 & m0) | ((unsigned long long)x1 & m1) |
                                             ((unsigned long long)x2 & m2));
   };
-  auto picki = [&](int x0, int x1, int x2) {
-    return (int)(((unsigned)x0 & (unsigned)m0) | ((unsigned)x1 & (unsigned)m1) | ((unsigned)x2 & (unsigned)m2));
-  };
-  s0.w.p0 = pick(g.w0.p0, g.w1.p0, g.w2.p0);
-  s0.w.p1 = pick(g.w0.p1, g.w1.p1, g.w2.p1);
-  s0.w.p2 = pick(g.w0.p2, g.w1.p2, g.w2.p2);
-  s0.w.p3 = pick(g.w0.p3, g.w1.p3, g.w2.p3);
-  s0.w.rows = picki(g.w0.rows, g.w1.rows, g.w2.rows);
-  s0.w.type = picki(g.w0.type, g.w1.type, g.w2.type);
-  s0.w.cols = g.w0.cols;
+  wa.p0 = pick(g.w0.p0, g.w1.p0, g.w2.p0);
+  wa.p1 = pick(g.w0.p1, g.w1.p1, g.w2.p1);
+  wa.p2 = pick(g.w0.p2, g.w1.p2, g.w2.p2);
+  wa.p3 = pick(g.w0.p3, g.w1.p3, g.w2.p3);
+  wa.rows = (int)(((unsigned)g.w0.rows & (unsigned)m0) | ((unsigned)g.w1.rows & (unsigned)m1) |
+                  ((unsigned)g.w2.rows & (unsigned)m2));
   out = reinterpret_cast<float*>(const_cast<uint8_t*>(pick(g.o0, g.o1, g.o2)));
-  s1.w = s0.w;
-  row0 = 2 * lt;
-  s0.row = row0;
-  s1.row = row0 + 1 < s0.w.rows ? row0 + 1 : s0.w.rows - 1;  // odd tail: computed twice, stored once
+  wb.p0 = wa.p0;
+  wb.p1 = wa.p1;
+  wb.p2 = wa.p2;
+  wb.p3 = wa.p3;
+  wb.rows = wa.rows;
+  ra = 2 * lt;
+  rb = ra + 1 < wa.rows ? ra + 1 : wa.rows - 1;  // odd tail: computed twice, stored once
 }
 
-template <bool NT>
-__device__ __forceinline__ void step_load(Step& st, const Stream& s0, const Stream& s1, int span, int nchunks,
-                                          int lane) {
-  const int chunk = (span << 6) + lane;
-  const unsigned cc = chunk < nchunks ? chunk : nchunks - 1;
-  chunk_load<NT>(s0, cc, st.r0);
-  chunk_load<NT>(s1, cc, st.r1);
-}
+template <int TYPE>
+struct Step {
+  Chunk<TYPE> c0, c1;
+  float r0, r1;  // residual values of the two rows (RESID launches only)
+};
 
-__device__ __forceinline__ void step_dot(const Step& st, int type0, int type1, int span, int nchunks, int lane,
-                                         const float* xs, float& acc0, float& acc1) {
-  const int chunk = (span << 6) + lane;
-  const bool act = chunk < nchunks;
-  const int cc = act ? chunk : nchunks - 1;
-  float x[32];
-  const f32x4* xp = reinterpret_cast<const f32x4*>(xs + cc * XS_STRIDE);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const f32x4 t = xp[i];
-    x[4 * i] = t[0]; x[4 * i + 1] = t[1]; x[4 * i + 2] = t[2]; x[4 * i + 3] = t[3];
-  }
-  const f32x4 sums = xp[8];
-  const float d0 = chunk_dot(type0, st.r0, x, sums[0], sums[1], cc & 7);
-  const float d1 = chunk_dot(type1, st.r1, x, sums[0], sums[1], cc & 7);
-  acc0 += act ? d0 : 0.0f;
-  acc1 += act ? d1 : 0.0f;
-}
+// what the consumer of a step needs to know about it (wave-uniform)
+struct StepMeta {
+  int sp, ra, rows;
+  float* out;
+};
 
-// ROLE only names the instantiation (tl_internal.h GemvRole) so that profiles separate the per-layer launches.
-template <bool PAIR, bool NT, int ROLE>
-__global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
-                                                                int t0, int t1, int t2) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// all row groups rg = first, first + stride, ... < total of one format class, for one wave.
+// Two cursors: the ISSUE cursor (irg, isp, wa/wb/ra/rb/out) runs one step ahead of the step being consumed, whose
+// facts travel in a StepMeta next to its register buffer. Every consume() directly follows an issue() in straight-line
+// code (the loop is peeled instead of making the prefetch conditional), so the compiler can wait with a COUNTED
+// vmcnt that leaves the prefetch in flight.
+// RESID: out[r] = resid[r] + y[r]. The two residual values are loaded at ISSUE time, ahead of the step's weight loads:
+// loads complete in order, so a load in the epilogue would drain the whole prefetch queue once per row group.
+template <int TYPE, bool PAIR, bool RESID, bool STAMP>
+__device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const XRegs& xr, float* smem, int first,
+                                          int stride, int total, int lane, unsigned long long* ts) {
   const float* xs = smem + XS_SCRATCH;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nchunks = a.cols >> 5;
   const int nspans = (nchunks + 63) >> 6;
-  const int total = PAIR ? t0 : (t0 + t1 + t2);
-  const int stride = gridDim.x * (blockDim.x >> 6);
-  const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, a.resid, t0, t1};
-
-  // wave-uniform cursor: row group rg (streams s0/s1), span sp
-  int rg = wave * gridDim.x + blockIdx.x, sp = 0;
-  Stream s0, s1;
-  float* out = nullptr;
-  int row0 = 0;
-  Step bufA, bufB;
-  const bool any = rg < total;
-  if (any) {  // first step's loads go out before x is staged: the HBM round trip overlaps the prologue
-    streams_of<PAIR>(g, rg, s0, s1, out, row0);
-    step_load<NT>(bufA, s0, s1, 0, nchunks, lane);
+  if (first >= total) {  // a wave without work only helps staging x
+    if (STAMP) ts[1] = __builtin_readcyclecounter();
+    stage_x_finish(a, xr, smem);
+    if (STAMP) ts[2] = __builtin_readcyclecounter();
+    return;
   }
-  stage_x(a, smem);
-  if (!any) return;
-
+  int irg = first, isp = 0;
+  QW wa = g.w0, wb = PAIR ? g.w1 : g.w0;
+  int ra = 0, rb = 0;
+  float* out = g.o0;
+  group_of<PAIR>(g, irg, wa, wb, ra, rb, out);
   float acc0 = 0.f, acc1 = 0.f;
-  // one step: prefetch the next step into `nxt`, consume `cur`; returns false when the wave is done
-  auto step = [&](Step& cur, Step& nxt) -> bool {
-    int nsp = sp + 1, nrg = rg;
-    if (nsp == nspans) {
-      nsp = 0;
-      nrg = rg + stride;
+
+  auto issue = [&](Step<TYPE>& st, StepMeta& m) {
+    m.sp = isp;
+    m.ra = ra;
+    m.rows = wa.rows;
+    m.out = out;
+    const int chunk = (isp << 6) + lane;
+    const unsigned cc = chunk < nchunks ? chunk : nchunks - 1;
+    if (RESID) {
+      st.r0 = ldg_f32(a.resid + ra);
+      st.r1 = ldg_f32(a.resid + rb);
     }
-    Stream n0 = s0, n1 = s1;
-    float* nout = out;
-    int nrow0 = row0;
-    const bool more = nrg < total;
-    if (more) {
-      if (nrg != rg) streams_of<PAIR>(g, nrg, n0, n1, nout, nrow0);
-      step_load<NT>(nxt, n0, n1, nsp, nchunks, lane);
+    st.c0.load(wa, ra, cc);
+    st.c1.load(wb, rb, cc);
+    if (++isp == nspans) {  // advance the issue cursor (scalar work, overlaps the loads)
+      isp = 0;
+      irg += stride;
+      if (irg < total) group_of<PAIR>(g, irg, wa, wb, ra, rb, out);
     }
-    step_dot(cur, s0.w.type, s1.w.type, sp, nchunks, lane, xs, acc0, acc1);
-    if (sp == nspans - 1) {  // row group complete: reduce, epilogue, store
+  };
+  auto consume = [&](const Step<TYPE>& st, const StepMeta& m) {
+    const int chunk = (m.sp << 6) + lane;
+    const bool act = chunk < nchunks;
+    const int cc = act ? chunk : nchunks - 1;
+    float x[32];
+    const f32x4* xp = reinterpret_cast<const f32x4*>(xs + cc * XS_STRIDE);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 t = xp[i];
+      x[4 * i] = t[0]; x[4 * i + 1] = t[1]; x[4 * i + 2] = t[2]; x[4 * i + 3] = t[3];
+    }
+    const f32x4 sums = xp[8];
+    const float d0 = st.c0.dot(x, sums[0], sums[1], cc & 7);
+    const float d1 = st.c1.dot(x, sums[0], sums[1], cc & 7);
+    acc0 += act ? d0 : 0.0f;
+    acc1 += act ? d1 : 0.0f;
+    if (m.sp == nspans - 1) {  // row group complete: reduce, epilogue, store
       const float y0 = wave_sum_lane63(acc0);
       const float y1 = wave_sum_lane63(acc1);
       if (lane == 63) {
         if (PAIR) {
           const float sg = 1.0f / (1.0f + expf(-y0));  // silu_cpu (utils.cpp:700-707), then * up (model.cpp:735)
-          out[row0] = (y0 * sg) * y1;
+          stg_f32(m.out + m.ra, (y0 * sg) * y1);
         } else {
-          out[row0] = g.resid ? g.resid[row0] + y0 : y0;
-          if (row0 + 1 < s0.w.rows) out[row0 + 1] = g.resid ? g.resid[row0 + 1] + y1 : y1;
+          stg_f32(m.out + m.ra, RESID ? st.r0 + y0 : y0);
+          if (m.ra + 1 < m.rows) stg_f32(m.out + m.ra + 1, RESID ? st.r1 + y1 : y1);
         }
       }
       acc0 = 0.f;
       acc1 = 0.f;
     }
-    rg = nrg;
-    sp = nsp;
-    s0 = n0;
-    s1 = n1;
-    out = nout;
-    row0 = nrow0;
-    return more;
   };
-  for (;;) {
-    if (!step(bufA, bufB)) break;
-    if (!step(bufB, bufA)) break;
+
+  // Software pipeline of depth one: the loads of step i+1 are in flight while step i is consumed. (Alternating two
+  // named buffers instead of the copy makes hipcc insert vmcnt(0) waits in front of unrelated register writes.)
+  Step<TYPE> cur, nxt;
+  StepMeta mc, mn;
+  issue(cur, mc);  // the first step's loads go out before x is staged: the HBM round trip overlaps the prologue
+  if (STAMP) ts[1] = __builtin_readcyclecounter();
+  stage_x_finish(a, xr, smem);
+  if (STAMP) ts[2] = __builtin_readcyclecounter();
+  while (irg < total) {
+    issue(nxt, mn);
+    consume(cur, mc);
+    if (STAMP && ts[3] == 0) ts[3] = __builtin_readcyclecounter();
+    cur = nxt;
+    mc = mn;
+  }
+  consume(cur, mc);
+  if (STAMP && ts[3] == 0) ts[3] = __builtin_readcyclecounter();
+}
+
+// TA: format of class A = segments [0, nsegA); TB: format of class B = segment nsegA (TL_NONE: no class B).
+// Waves [0, wavesA) of every workgroup run class A, the others class B.
+// ROLE only names the instantiation (tl_internal.h GemvRole) so that profiles separate the per-layer launches.
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
+__global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
+                                                                int t0, int t1, int t2, int nsegA, int wavesA) {
+  constexpr bool RESID = ROLE == GEMV_ATTN_OUT || ROLE == GEMV_DOWN;  // the roles launched with a residual
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned long long ts[5] = {0, 0, 0, 0, 0}, rt0 = 0;
+  if (STAMP) {
+    ts[0] = __builtin_readcyclecounter();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  XRegs xr;
+  stage_x_issue(a, xr);
+  if (TB == TL_NONE || wave < wavesA) {
+    const int wA = TB == TL_NONE ? nwaves : wavesA;
+    const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
+    const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, t0, nsegA >= 2 ? t1 : 0x3fffffff};
+    run_class<TA, PAIR, RESID, STAMP>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane, ts);
+  } else if (TB != TL_NONE) {
+    constexpr int TBB = TB == TL_NONE ? TA : TB;
+    const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
+    const int tb = nsegA == 1 ? t1 : t2;
+    const Segs g = {sb.w, sb.w, sb.w, sb.out, sb.out, sb.out, 0x3fffffff, 0x3fffffff};
+    run_class<TBB, false, false, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
+                                 gridDim.x * (nwaves - wavesA), tb, lane, ts);
+  }
+  if (STAMP && lane == 0 && ts[3] != 0) {
+    ts[4] = __builtin_readcyclecounter();
+    unsigned long long* o = a.stamps + 8 * (size_t)(wave * gridDim.x + blockIdx.x);
+    for (int i = 0; i < 5; ++i) o[i] = ts[i];
+    o[5] = __builtin_amdgcn_s_memrealtime();
+    o[6] = rt0;
   }
 }
 
@@ -411,7 +473,7 @@ __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__
 
 static int g_gemv_setup_done = 0;
 static int g_num_cus = 256;
-static int g_nt = 1, g_max_waves = 16;
+static int g_max_waves = 16;
 
 static int gemv_setup() {
   if (g_gemv_setup_done) return 0;
@@ -420,8 +482,7 @@ static int gemv_setup() {
   hipDeviceProp_t prop;
   TL_HIP(hipGetDeviceProperties(&prop, dev));
   g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  if (const char* e = getenv("TL_GEMV_NT")) g_nt = atoi(e) != 0;  // tuning knobs (experiments only)
-  if (const char* e = getenv("TL_GEMV_WAVES")) {
+  if (const char* e = getenv("TL_GEMV_WAVES")) {  // tuning knob (experiments only)
     const int w = atoi(e);
     if (w >= 1 && w <= 16) g_max_waves = w;
   }
@@ -429,29 +490,69 @@ static int gemv_setup() {
   return 0;
 }
 
-template <bool PAIR, bool NT, int ROLE>
-static int gemv_launch_one(const GemvArgs& a, int grid, int threads, size_t lds, const int* t, hipStream_t s) {
+struct Launch {
+  GemvSeg seg[3];
+  GemvVec v;
+  int t[3];
+  int nsegA, wavesA;
+  int grid, threads;
+  size_t lds;
+};
+
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
+static int gemv_launch_one(const Launch& L, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<PAIR, NT, ROLE>),
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<TA, TB, PAIR, ROLE, STAMP>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  const GemvVec v = {a.x, a.norm_w, a.resid, a.eps, a.cols};
-  gemv_kernel<PAIR, NT, ROLE><<<grid, threads, lds, s>>>(a.seg[0], a.seg[1], a.seg[2], v, t[0], t[1], t[2]);
+  gemv_kernel<TA, TB, PAIR, ROLE, STAMP><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], L.v, L.t[0],
+                                                                           L.t[1], L.t[2], L.nsegA, L.wavesA);
   return 0;
 }
 
-template <bool NT>
-static int gemv_launch_role(const GemvArgs& a, int grid, int threads, size_t lds, const int* t, hipStream_t s) {
-  if (a.pair) return gemv_launch_one<true, NT, GEMV_GATE_UP>(a, grid, threads, lds, t, s);
-  switch (a.role) {
-    case GEMV_QKV: return gemv_launch_one<false, NT, GEMV_QKV>(a, grid, threads, lds, t, s);
-    case GEMV_ATTN_OUT: return gemv_launch_one<false, NT, GEMV_ATTN_OUT>(a, grid, threads, lds, t, s);
-    case GEMV_DOWN: return gemv_launch_one<false, NT, GEMV_DOWN>(a, grid, threads, lds, t, s);
-    case GEMV_LM_HEAD: return gemv_launch_one<false, NT, GEMV_LM_HEAD>(a, grid, threads, lds, t, s);
-    default: return gemv_launch_one<false, NT, GEMV_GENERIC>(a, grid, threads, lds, t, s);
+template <int TA, int ROLE>
+static int gemv_launch_plain(const Launch& L, hipStream_t s) {
+  return gemv_launch_one<TA, TL_NONE, false, ROLE>(L, s);
+}
+
+template <int ROLE>
+static int gemv_launch_type(int ta, const Launch& L, hipStream_t s) {
+  switch (ta) {
+    case TL_Q4_K: return gemv_launch_plain<TL_Q4_K, ROLE>(L, s);
+    case TL_Q6_K: return gemv_launch_plain<TL_Q6_K, ROLE>(L, s);
+    case TL_Q8_0: return gemv_launch_plain<TL_Q8_0, ROLE>(L, s);
+    case TL_Q8_K: return gemv_launch_plain<TL_Q8_K, ROLE>(L, s);
+    default: tl_set_error("gemv: unsupported weight type %d", ta); return 2;
   }
+}
+
+static int gemv_launch_pair(int ta, const Launch& L, hipStream_t s) {
+  switch (ta) {
+    case TL_Q4_K: return gemv_launch_one<TL_Q4_K, TL_NONE, true, GEMV_GATE_UP>(L, s);
+    case TL_Q6_K: return gemv_launch_one<TL_Q6_K, TL_NONE, true, GEMV_GATE_UP>(L, s);
+    case TL_Q8_0: return gemv_launch_one<TL_Q8_0, TL_NONE, true, GEMV_GATE_UP>(L, s);
+    case TL_Q8_K: return gemv_launch_one<TL_Q8_K, TL_NONE, true, GEMV_GATE_UP>(L, s);
+    default: tl_set_error("gemv: unsupported weight type %d", ta); return 2;
+  }
+}
+
+__global__ void swiglu_inplace_kernel(float* __restrict__ g, const float* __restrict__ u, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x = g[i];
+  g[i] = (x * (1.0f / (1.0f + expf(-x)))) * u[i];  // utils.cpp:704-705, model.cpp:735
+}
+
+static int gemv_geometry(Launch& L, int total) {
+  // one workgroup per CU, all resident at once; small problems use fewer CUs / fewer waves per workgroup
+  L.grid = total < g_num_cus ? total : g_num_cus;
+  int waves = (total + L.grid - 1) / L.grid;
+  if (waves > g_max_waves) waves = g_max_waves;
+  if (waves < 4) waves = 4;  // the x staging pass wants a few waves
+  L.threads = waves * 64;
+  return waves;
 }
 
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
@@ -478,19 +579,118 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
     TL_HIP(hipGetLastError());
     return 0;
   }
-  const size_t lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
-  TL_REQUIRE(lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, lds);
-  int t[3] = {0, 0, 0};
-  for (int i = 0; i < a.nseg; ++i) t[i] = a.pair ? a.seg[i].w.rows : (a.seg[i].w.rows + 1) / 2;
-  const int total = a.pair ? t[0] : t[0] + t[1] + t[2];
-  // one workgroup per CU, all resident at once; small problems use fewer CUs / fewer waves per workgroup
-  int grid = total < g_num_cus ? total : g_num_cus;
-  int waves = (total + grid - 1) / grid;
-  if (waves > g_max_waves) waves = g_max_waves;
-  if (waves < 4) waves = 4;  // the x staging pass wants a few waves
-  const int threads = waves * 64;
-  TL_TRY(g_nt ? gemv_launch_role<true>(a, grid, threads, lds, t, s) : gemv_launch_role<false>(a, grid, threads, lds, t, s));
+  Launch L = {};
+  L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
+  TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
+  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr};
+  for (int i = 0; i < 3; ++i) L.seg[i] = a.seg[i < a.nseg ? i : 0];
+  const int ta = a.seg[0].w.type;
+
+  if (a.pair) {
+    if (a.seg[1].w.type != ta) {
+      // gate and up in different formats (not produced by any mix the reference loads): two launches + SwiGLU.
+      // The up projection goes through a.seg[1].out, which the caller must then provide.
+      TL_REQUIRE(a.seg[1].out, "gemv: a mixed-format gate/up pair needs a scratch output for the up projection");
+      GemvArgs g1 = a, g2 = a;
+      g1.pair = g2.pair = 0;
+      g1.nseg = g2.nseg = 1;
+      g2.seg[0] = a.seg[1];
+      g1.role = g2.role = GEMV_GENERIC;
+      TL_TRY(tl_launch_gemv(g1, s));
+      TL_TRY(tl_launch_gemv(g2, s));
+      const int n = a.seg[0].w.rows;
+      swiglu_inplace_kernel<<<(n + 255) / 256, 256, 0, s>>>(a.seg[0].out, a.seg[1].out, n);
+      TL_HIP(hipGetLastError());
+      return 0;
+    }
+    L.t[0] = a.seg[0].w.rows;
+    L.nsegA = 2;
+    gemv_geometry(L, L.t[0]);
+    TL_TRY(gemv_launch_pair(ta, L, s));
+    TL_HIP(hipGetLastError());
+    return 0;
+  }
+
+  // format classes: segments [0, nsegA) share seg[0]'s format; at most ONE trailing segment may differ
+  int nsegA = 1;
+  while (nsegA < a.nseg && a.seg[nsegA].w.type == ta) ++nsegA;
+  const bool classB = nsegA < a.nseg;
+  if (classB && !(nsegA == a.nseg - 1 && ta == TL_Q4_K && a.seg[nsegA].w.type == TL_Q6_K)) {
+    // any other mixture: one launch per segment (correct, just not fused)
+    for (int i = 0; i < a.nseg; ++i) {
+      GemvArgs one = a;
+      one.nseg = 1;
+      one.seg[0] = a.seg[i];
+      TL_TRY(tl_launch_gemv(one, s));
+    }
+    return 0;
+  }
+  double bytesA = 0.0, bytesB = 0.0;
+  int totalA = 0;
+  for (int i = 0; i < a.nseg; ++i) {
+    L.t[i] = (a.seg[i].w.rows + 1) / 2;
+    const double b = (double)a.seg[i].w.rows * a.cols / tl_type_block_elems(a.seg[i].w.type) *
+                     (double)tl_type_block_bytes(a.seg[i].w.type);
+    if (i < nsegA) {
+      bytesA += b;
+      totalA += L.t[i];
+    } else {
+      bytesB += b;
+    }
+  }
+  L.nsegA = nsegA;
+  const int total = classB ? totalA + L.t[nsegA] : totalA;
+  const int waves = gemv_geometry(L, total);
+  L.wavesA = waves;
+  if (classB) {
+    int wa = (int)(waves * bytesA / (bytesA + bytesB) + 0.5);
+    if (wa < 1) wa = 1;
+    if (wa > waves - 1) wa = waves - 1;
+    L.wavesA = wa;
+    TL_TRY((gemv_launch_one<TL_Q4_K, TL_Q6_K, false, GEMV_QKV>(L, s)));
+    TL_HIP(hipGetLastError());
+    return 0;
+  }
+  int rc = 0;
+  int role = a.role;  // the residual epilogue is compiled into the ATTN_OUT / DOWN instantiations only
+  if (a.resid && role != GEMV_ATTN_OUT && role != GEMV_DOWN) role = GEMV_ATTN_OUT;
+  if (!a.resid && (role == GEMV_ATTN_OUT || role == GEMV_DOWN)) role = GEMV_GENERIC;
+  switch (role) {
+    case GEMV_QKV: rc = gemv_launch_type<GEMV_QKV>(ta, L, s); break;
+    case GEMV_ATTN_OUT: rc = gemv_launch_type<GEMV_ATTN_OUT>(ta, L, s); break;
+    case GEMV_DOWN: rc = gemv_launch_type<GEMV_DOWN>(ta, L, s); break;
+    case GEMV_LM_HEAD: rc = gemv_launch_type<GEMV_LM_HEAD>(ta, L, s); break;
+    default: rc = gemv_launch_type<GEMV_GENERIC>(ta, L, s); break;
+  }
+  TL_TRY(rc);
   TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// Diagnostic hook (no counterpart in the reference): one tl_matvec_q-shaped launch of the stamped instantiation;
+// stamps_dev receives 8 u64 per wave slot (grid * waves-per-block slots, <= 256 * 16): shader-clock stamps at kernel
+// entry, after the first loads were issued, after x staging, after the first step, at wave end; [5], [6] = realtime
+// at wave end / entry. Q4_K and Q6_K only.
+extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, unsigned long long* stamps_dev,
+                                    int* grid_out, int* waves_out, void* stream) {
+  TL_REQUIRE(w && x_dev && y_dev && stamps_dev && (w->type == TL_Q4_K || w->type == TL_Q6_K),
+             "tl_debug_gemv_stamps: bad argument (Q4_K / Q6_K only)");
+  TL_TRY(gemv_setup());
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Launch L = {};
+  L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(w->cols / 32) * XS_STRIDE);
+  TL_REQUIRE(L.lds <= 160 * 1024, "tl_debug_gemv_stamps: cols %d too large", w->cols);
+  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev};
+  for (int i = 0; i < 3; ++i) L.seg[i] = GemvSeg{qw_view(w), y_dev};
+  L.t[0] = (w->rows + 1) / 2;
+  L.nsegA = 1;
+  L.wavesA = gemv_geometry(L, L.t[0]);
+  TL_HIP(hipMemsetAsync(stamps_dev, 0, sizeof(unsigned long long) * 8 * (size_t)L.grid * (L.threads / 64), s));
+  if (w->type == TL_Q4_K) TL_TRY((gemv_launch_one<TL_Q4_K, TL_NONE, false, GEMV_GENERIC, true>(L, s)));
+  else TL_TRY((gemv_launch_one<TL_Q6_K, TL_NONE, false, GEMV_GENERIC, true>(L, s)));
+  TL_HIP(hipGetLastError());
+  if (grid_out) *grid_out = L.grid;
+  if (waves_out) *waves_out = L.threads / 64;
   return 0;
 }
 

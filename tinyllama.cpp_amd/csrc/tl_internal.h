@@ -96,5 +96,28 @@ int tl_launch_rope_kv(float* q, float* k, const float* v, float* kcache, float* 
                       int nkv, int hd, const int* pos_dev, int max_pos, hipStream_t s);
 int tl_launch_attn_decode(const float* q, const float* kc, const float* vc, float* out, int nh, int nkv, int hd,
                           int seq_len, const int* pos_dev, int max_seq, float scale, hipStream_t s);
+// split decode attention (tl_attn.hip)
+struct AttnArgs {
+  const float* q;        // [nh][hd]; FUSE: un-rotated (rotated into LDS only)
+  const float* k;        // FUSE only: un-rotated k [nkv][hd] of the new position
+  const float* v;        // FUSE only: v [nkv][hd] of the new position
+  float* kc;             // K cache [max_seq][nkv][hd] (FUSE: position pos is written)
+  float* vc;             // V cache
+  const float* table;    // FUSE only: RoPE table [max_seq][hd/2][2]
+  float* out;            // [nh][hd]
+  float* ws;             // partials: tl_attn_ws_floats(nh, hd, nsplit_max) floats
+  int* counters;         // [nkv] arrival counters, zero between launches
+  int nh, nkv, hd;
+  int seq_len;           // positions 0..seq_len-1 when pos_dev == NULL
+  const int* pos_dev;    // != NULL: the new position lives on the device (graph replay); seq_len = *pos_dev + 1
+  int max_seq;
+  float scale;
+  int split_len, nsplit_max;
+};
+bool tl_attn_split_supported(int nh, int nkv, int hd);
+void tl_attn_geometry(int max_seq, int nkv, int* split_len, int* nsplit);
+size_t tl_attn_ws_floats(int nh, int hd, int nsplit);
+int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s);
+
 int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, const int* n_hist_dev, float penalty,
                      hipStream_t s);

@@ -48,6 +48,10 @@ struct tl_model {
   // workspaces
   float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *h = nullptr, *logits = nullptr;
   float* rope = nullptr;
+  float* attn_ws = nullptr;    // split-attention partials
+  int* attn_counters = nullptr;
+  int attn_split_len = 0, attn_nsplit = 0;
+  bool attn_split = false;
   int* state = nullptr;  // DevState header + history ring
   int hist_cap = 0;
   hipStream_t stream = nullptr;
@@ -115,6 +119,8 @@ extern "C" int tl_model_free(tl_model* m) {
   float* bufs[] = {m->out_norm, m->kv_base, m->x, m->q, m->k, m->v, m->att, m->h, m->logits, m->rope};
   for (float* b : bufs) hipFree(b);
   hipFree(m->state);
+  hipFree(m->attn_ws);
+  hipFree(m->attn_counters);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -264,11 +270,34 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
     a.role = GEMV_QKV;
     TL_TRY(tl_launch_gemv(a, s));
     PROF_MARK(1);
-    TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, c.num_attention_heads,
-                             c.num_key_value_heads, m->head_dim, pos_dev, c.max_position_embeddings, s));
-    PROF_MARK(2);
-    TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, c.num_attention_heads, c.num_key_value_heads,
-                                 m->head_dim, 0, pos_dev, c.max_position_embeddings, scale, s));
+    if (m->attn_split) {  // RoPE + KV write + split attention in one launch
+      AttnArgs t = {};
+      t.q = m->q;
+      t.k = m->k;
+      t.v = m->v;
+      t.kc = m->kc(l);
+      t.vc = m->vc(l);
+      t.table = m->rope;
+      t.out = m->att;
+      t.ws = m->attn_ws;
+      t.counters = m->attn_counters;
+      t.nh = c.num_attention_heads;
+      t.nkv = c.num_key_value_heads;
+      t.hd = m->head_dim;
+      t.pos_dev = pos_dev;
+      t.max_seq = c.max_position_embeddings;
+      t.scale = scale;
+      t.split_len = m->attn_split_len;
+      t.nsplit_max = m->attn_nsplit;
+      PROF_MARK(2);
+      TL_TRY(tl_launch_attn_split(t, true, s));
+    } else {
+      TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, c.num_attention_heads,
+                               c.num_key_value_heads, m->head_dim, pos_dev, c.max_position_embeddings, s));
+      PROF_MARK(2);
+      TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, c.num_attention_heads, c.num_key_value_heads,
+                                   m->head_dim, 0, pos_dev, c.max_position_embeddings, scale, s));
+    }
     PROF_MARK(3);
     GemvArgs o = {};
     o.seg[0] = {qw_view(L.q[TL_T_ATTN_OUTPUT]), m->x};
@@ -357,6 +386,13 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->logits, sizeof(float) * V));
   TL_HIP(hipMalloc(&m->rope, sizeof(float) * P * m->head_dim));
   TL_TRY(tl_rope_table_upload(m->rope, (int)P, m->head_dim, c.rope_theta, m->stream));
+  m->attn_split = tl_attn_split_supported(c.num_attention_heads, c.num_key_value_heads, m->head_dim);
+  if (m->attn_split) {
+    tl_attn_geometry((int)P, c.num_key_value_heads, &m->attn_split_len, &m->attn_nsplit);
+    TL_HIP(hipMalloc(&m->attn_ws, sizeof(float) * tl_attn_ws_floats(c.num_attention_heads, m->head_dim, m->attn_nsplit)));
+    TL_HIP(hipMalloc(&m->attn_counters, sizeof(int) * (size_t)c.num_key_value_heads));
+    TL_HIP(hipMemsetAsync(m->attn_counters, 0, sizeof(int) * (size_t)c.num_key_value_heads, m->stream));
+  }
   m->hist_cap = (int)P + 64;
   TL_HIP(hipMalloc(&m->state, sizeof(int) * (kStateHeaderInts + m->hist_cap)));
   TL_HIP(hipMemsetAsync(m->state, 0, sizeof(int) * (kStateHeaderInts + m->hist_cap), m->stream));

@@ -72,6 +72,9 @@ __device__ __forceinline__ float scale_field(unsigned h) {
 
 // dot of 4 unpacked bytes with 4 consecutive x
 __device__ __forceinline__ float dot4(unsigned v, const float* x, float acc) {
+  // opaque to the optimiser: with the nibble masks visible it narrows "(v >> 8) & 0xff" to "& 0x0f" and loses the
+  // v_cvt_f32_ubyte1..3 byte-select patterns (a shift + an and + ubyte0 per weight instead of one convert)
+  asm("" : "+v"(v));
   acc = fmaf(ub0(v), x[0], acc);
   acc = fmaf(ub1(v), x[1], acc);
   acc = fmaf(ub2(v), x[2], acc);
@@ -82,6 +85,16 @@ __device__ __forceinline__ float dot4(unsigned v, const float* x, float acc) {
 // Non-temporal load through an explicitly GLOBAL pointer: the segment pointers pass through integer arithmetic
 // (group_of), after which the compiler no longer knows their address space and would emit flat_load, whose
 // completion is unordered and forces vmcnt(0) waits.
+// acc + f16(lo / hi half of p) * x, all in FP32 (v_fma_mix_f32: op_sel_hi marks the fp16 source, op_sel its half)
+__device__ __forceinline__ float fma_mix_lo(unsigned p, float x, float acc) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(p), "v"(x));
+  return acc;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned p, float x, float acc) {
+  asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(p), "v"(x));
+  return acc;
+}
+
 template <typename T>
 __device__ __forceinline__ T ldg(const uint8_t* base, unsigned byte_off) {
   typedef const T __attribute__((address_space(1))) * gptr;
@@ -110,18 +123,31 @@ struct Chunk<TL_Q4_K> {
     a = ldg<u32x4>(w.p0 + r * (cols >> 1), c * 16u);
     b = ldg<u32x4>(w.p1 + r * (cols >> 4), (c >> 3) * 16u);
   }
+  // Nibbles never become integers-to-convert: a masked dword IS two fp16 subnormals (n * 2^-24 in each half when
+  // the nibble sits in bits 0-3 of the half, n * 2^-20 in bits 4-7), and v_fma_mix_f32 multiplies an fp16 half by an
+  // fp32 x into an fp32 accumulator exactly. 5 bit-ops + 8 FMAs per 8 weights instead of 3 + 8 converts + 8 FMAs.
+  // Nibble i of dword w is weight 8w + i/2 (i even) or 8w + 4 + i/2 (i odd), see tl_internal.h.
   __device__ __forceinline__ float dot(const float* x, float s0, float s1, int j) const {
-    float a0 = 0.f, a1 = 0.f;
+    float aA = 0.f, aB = 0.f;  // aA: nibbles scaled 2^-24, aB: nibbles scaled 2^-20
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-      const unsigned lo = a[w] & 0x0F0F0F0Fu, hi = (a[w] >> 4) & 0x0F0F0F0Fu;
-      a0 = dot4(lo, x + 8 * w, a0);
-      a1 = dot4(hi, x + 8 * w + 4, a1);
+      const unsigned v = a[w], s = v >> 8;
+      const unsigned m0 = v & 0x000F000Fu, m1 = v & 0x00F000F0u, m2 = s & 0x000F000Fu, m3 = s & 0x00F000F0u;
+      const float* xw = x + 8 * w;
+      aA = fma_mix_lo(m0, xw[0], aA);
+      aB = fma_mix_lo(m1, xw[4], aB);
+      aA = fma_mix_lo(m2, xw[1], aA);
+      aB = fma_mix_lo(m3, xw[5], aB);
+      aA = fma_mix_hi(m0, xw[2], aA);
+      aB = fma_mix_hi(m1, xw[6], aB);
+      aA = fma_mix_hi(m2, xw[3], aA);
+      aB = fma_mix_hi(m3, xw[7], aB);
     }
+    const float q = fmaf(aB, 0.0625f, aA) * 16777216.0f;  // sum(nibble * x), exact power-of-two rescale
     const float d = half_to_float(b[0] & 0xffffu), dmin = half_to_float(b[0] >> 16);
     const unsigned sc = ((b[1] >> (4 * j)) & 15u) | (((b[3] >> (2 * j)) & 3u) << 4);
     const unsigned mn = ((b[2] >> (4 * j)) & 15u) | (((b[3] >> (16 + 2 * j)) & 3u) << 4);
-    return (d * (float)sc) * (a0 + a1) - (dmin * (float)mn) * (s0 + s1);
+    return (d * (float)sc) * q - (dmin * (float)mn) * (s0 + s1);
   }
 };
 

@@ -8,14 +8,21 @@
 //
 // Shape (HBM/latency-bound byte work, no MFMA):
 //   - grid (kv head, sequence split): one workgroup serves ALL query heads of a kv head (GQA group), so every K/V
-//     byte is read once; a split is SL consecutive positions, chosen so that kv_heads x splits ~ the CU count at the
-//     longest context the cache holds;
-//   - a K/V row is read by HD/4 lanes x 16 B (one or two 256/512-B rows per wave load), 4 rows per lane in flight;
-//   - splits that hold positions write (max, sum, unnormalised out) partials; the last workgroup of a kv head to arrive
-//     (agent-scope release / counter / acquire) combines them. A single active split writes the result directly;
+//     byte is read once; a split is max(32, pow2(len / 32)) positions (tl_attn_split_len): at most 32 splits, so that
+//     8 kv heads fill 256 CUs from 1024 positions on while short contexts still spread over tens of CUs (one CU only
+//     pulls ~25-50 GB/s);
+//   - a K/V row is read by HD/4 lanes x 16 B (two or four rows per wave load); the K AND V rows of a batch (up to 16 of
+//     each per lane) are in flight together and folded into a running (max, sum, out) per lane group (online softmax),
+//     so a split of 256 positions costs one memory round trip;
+//   - every split writes a (max, sum, unnormalised out) partial per head; the partials are combined at the next kernel
+//     boundary: in the x-staging prologue of the attn_output GEMV (tl_gemv.hip), or by attn_combine_kernel for the
+//     operator-level API. (An in-launch combine by the last-arriving workgroup costs a release fence, an atomic and an
+//     acquire fence, ~4 us, more than the attention itself at short context.)
 //   - FUSE: the workgroup rotates its query heads into LDS; the split that owns the new position rotates k, writes
 //     K/V of that position into the cache and takes that position's score/value from LDS instead of from memory.
 #include <math.h>
+
+#include <type_traits>
 
 #include "tl_internal.h"
 
@@ -23,19 +30,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int ATT_NW = 8;           // waves per workgroup
+constexpr int ATT_NW = 8;  // waves per workgroup (512 threads: 256 VGPRs per lane for the rows in flight)
 constexpr int ATT_THREADS = ATT_NW * 64;
-constexpr int ATT_U = 4;            // K/V rows in flight per lane
 
-__device__ __forceinline__ float wmax64(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+__device__ __forceinline__ float safe_exp_diff(float m, float m_new) {  // exp(m - m_new), 0 when m is -inf
+  return m == -INFINITY ? 0.f : expf(m - m_new);
 }
 
 // adjacent-pair rotation (utils.cpp:462-486); contraction off: each product is rounded separately as on the host
@@ -47,28 +46,28 @@ __device__ __forceinline__ void rope2(float a, float b, float c, float s, float&
 
 template <int HD, int G, bool FUSE>
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs a) {
-  constexpr int LP = HD / 4;    // lanes per K/V row
-  constexpr int PP = 64 / LP;   // rows per wave load
+  constexpr int LP = HD / 4;             // lanes per K/V row
+  constexpr int PP = 64 / LP;            // rows per wave load
+  constexpr int U = G >= 8 ? 8 : 16;     // K and V rows in flight per lane: 256 rows per batch and workgroup
+  constexpr int RECL = HD + 4;           // partial record: out[HD], max, sum, 2 pad (16-B aligned)
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int SL = a.split_len;
-  float* qs = sm;                      // [G][HD]
-  float* kr = qs + G * HD;             // [HD] rotated k of the new position (FUSE owner)
-  float* vr = kr + HD;                 // [HD]
-  float* red = vr + HD;                // 64 floats: m[g] at g, l[g] at 8 + g, flags at 32
-  float* sc = red + 64;                // [G][SL]
-  float* part = sc + G * SL;           // [ATT_NW][G][HD]
+  float* qs = sm;                        // [G][HD]
+  float* kr = qs + G * HD;               // [HD] rotated k of the new position (FUSE owner)
+  float* vr = kr + HD;                   // [HD]
+  float* red = vr + HD;                  // 64 floats: M[g] at g, 1/L or L at 8 + g, flag at 32
+  float* part = red + 64;                // [ATT_NW][G][RECL]
   const int kvh = blockIdx.x, split = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = a.pos_dev ? *a.pos_dev : a.seq_len - 1;
   const int len = pos + 1;
+  const int SL = tl_attn_split_len(len);
   const int active = (len + SL - 1) / SL;
-  if (split >= active || pos < 0 || pos >= a.max_seq) return;
+  if (split >= active || pos < 0 || pos >= a.max_seq) return;  // (the combine only reads splits < active)
   const int kv_dim = a.nkv * HD;
   const int t0 = split * SL;
   const int t1 = len < t0 + SL ? len : t0 + SL;
   const bool owner = FUSE && split == active - 1;  // this split holds the new position, still only in registers
-  const int n = t1 - t0;                           // positions of this split
-  const int ncache = owner ? n - 1 : n;            // ... of which come from the cache
+  const int ncache = owner ? t1 - t0 - 1 : t1 - t0;  // positions of this split that come from the cache
 
   // ---- phase 0: query heads (and the new k / v) into LDS ---------------------------------------------------
   constexpr int half = HD / 2;
@@ -101,175 +100,164 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   }
   __syncthreads();
 
-  // ---- phase 1: scores ------------------------------------------------------------------------------------
+  // ---- phase 1: one pass over the rows with a running (max, sum, out) per lane group (online softmax) ----------
   const int sub = lane / LP, ln = lane % LP;
-  f32x4 qf[G];
+  f32x4 qf[G], acc[G];
+  float m[G], l[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qs + g * HD + 4 * ln);
-  const float* kbase = a.kc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
-  const float* vbase = a.vc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
-  for (int base = 0; base < ncache; base += ATT_NW * PP * ATT_U) {
-    f32x4 kk[ATT_U];
-    int idx[ATT_U];
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {  // unconditional (clamped) loads: all ATT_U rows are in flight together
-      idx[u] = base + (u * ATT_NW + wave) * PP + sub;
-      const int ic = idx[u] < ncache ? idx[u] : ncache - 1;
-      kk[u] = *reinterpret_cast<const f32x4*>(kbase + (size_t)ic * kv_dim);
-    }
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        float s = (qf[g][0] * kk[u][0] + qf[g][1] * kk[u][1]) + (qf[g][2] * kk[u][2] + qf[g][3] * kk[u][3]);
-#pragma unroll
-        for (int o = LP / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-        if (ln == 0 && idx[u] < ncache) sc[g * SL + idx[u]] = s * a.scale;
-      }
-    }
+  for (int g = 0; g < G; ++g) {
+    qf[g] = *reinterpret_cast<const f32x4*>(qs + g * HD + 4 * ln);
+    acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[g] = -INFINITY;
+    l[g] = 0.f;
   }
-  if (owner && wave == 0) {  // the new position, from LDS
-    const f32x4 kk = *reinterpret_cast<const f32x4*>(kr + 4 * ln);
+  // rows [r0, r0 + cnt) of `kk`/`vv` hold valid[u]; folds them into the running state
+  auto fold = [&](const f32x4* kk, const f32x4* vv, const bool* valid, auto cnt_c) {
+    constexpr int cnt = decltype(cnt_c)::value;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      float s = (qf[g][0] * kk[0] + qf[g][1] * kk[1]) + (qf[g][2] * kk[2] + qf[g][3] * kk[3]);
+      float s[cnt];
+      float mx = m[g];
 #pragma unroll
-      for (int o = LP / 2; o >= 1; o >>= 1) s += __shfl_xor(s, o);
-      if (lane == 0) sc[g * SL + (n - 1)] = s * a.scale;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 2: per-head max / exp / sum over the split --------------------------------------------------------
-  for (int g = wave; g < G; g += ATT_NW) {
-    float m = -INFINITY;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, sc[g * SL + i]);
-    m = wmax64(m);
-    float l = 0.f;
-    for (int i = lane; i < n; i += 64) {
-      const float e = expf(sc[g * SL + i] - m);
-      sc[g * SL + i] = e;
-      l += e;
-    }
-    l = wsum64(l);
-    if (lane == 0) {
-      red[g] = m;
-      red[8 + g] = l;
-    }
-  }
-  __syncthreads();
-
-  // ---- phase 3: out[g][:] = sum_t p[g][t] V[t][:] ------------------------------------------------------------------
-  f32x4 acc[G];
+      for (int u = 0; u < cnt; ++u) {
+        float d = (qf[g][0] * kk[u][0] + qf[g][1] * kk[u][1]) + (qf[g][2] * kk[u][2] + qf[g][3] * kk[u][3]);
 #pragma unroll
-  for (int g = 0; g < G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int base = 0; base < ncache; base += ATT_NW * PP * ATT_U) {
-    f32x4 vv[ATT_U];
-    int idx[ATT_U];
+        for (int o = LP / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        s[u] = valid[u] ? d * a.scale : -INFINITY;
+        mx = fmaxf(mx, s[u]);
+      }
+      if (mx == -INFINITY) continue;  // nothing valid yet (uniform over the lane group)
+      const float corr = safe_exp_diff(m[g], mx);
+      m[g] = mx;
+      l[g] *= corr;
+      acc[g][0] *= corr; acc[g][1] *= corr; acc[g][2] *= corr; acc[g][3] *= corr;
 #pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-      idx[u] = base + (u * ATT_NW + wave) * PP + sub;
-      const int ic = idx[u] < ncache ? idx[u] : ncache - 1;
-      vv[u] = *reinterpret_cast<const f32x4*>(vbase + (size_t)ic * kv_dim);
-    }
-#pragma unroll
-    for (int u = 0; u < ATT_U; ++u) {
-      const bool ok = idx[u] < ncache;
-      const int ic = ok ? idx[u] : 0;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float p = ok ? sc[g * SL + ic] : 0.f;
+      for (int u = 0; u < cnt; ++u) {
+        const float p = valid[u] ? expf(s[u] - mx) : 0.f;
+        l[g] += p;
         acc[g][0] = fmaf(p, vv[u][0], acc[g][0]);
         acc[g][1] = fmaf(p, vv[u][1], acc[g][1]);
         acc[g][2] = fmaf(p, vv[u][2], acc[g][2]);
         acc[g][3] = fmaf(p, vv[u][3], acc[g][3]);
       }
     }
-  }
-  if (owner && wave == 0 && sub == 0) {
-    const f32x4 vv = *reinterpret_cast<const f32x4*>(vr + 4 * ln);
+  };
+  const float* kbase = a.kc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
+  const float* vbase = a.vc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
+  // one batch of UC row slots per lane group: slot u holds row base + (u * NW + wave) * PP + sub (rows go round the
+  // waves first, so short splits use few slots in every wave). UC is compile-time: 2, 4, 8 or U.
+  auto batch = [&](int base, auto uc_c) {
+    constexpr int UC = decltype(uc_c)::value;
+    f32x4 kk[UC], vv[UC];
+    bool valid[UC];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const float p = sc[g * SL + (n - 1)];
-      acc[g][0] = fmaf(p, vv[0], acc[g][0]);
-      acc[g][1] = fmaf(p, vv[1], acc[g][1]);
-      acc[g][2] = fmaf(p, vv[2], acc[g][2]);
-      acc[g][3] = fmaf(p, vv[3], acc[g][3]);
+    for (int u = 0; u < UC; ++u) {  // unconditional (clamped) loads: all K and V rows of the batch in flight together
+      const int idx = base + (u * ATT_NW + wave) * PP + sub;
+      valid[u] = idx < ncache;
+      const size_t off = (size_t)(valid[u] ? idx : ncache - 1) * kv_dim;
+      kk[u] = *reinterpret_cast<const f32x4*>(kbase + off);
+      vv[u] = *reinterpret_cast<const f32x4*>(vbase + off);
     }
+    fold(kk, vv, valid, uc_c);
+  };
+  for (int base = 0; base < ncache; base += ATT_NW * PP * U) {
+    const int mine = ncache - base - wave * PP;  // rows at or after this wave's first slot (wave-uniform)
+    if (mine <= 0) continue;
+    const int slots = (mine + ATT_NW * PP - 1) / (ATT_NW * PP);
+    if (slots <= 2) batch(base, std::integral_constant<int, 2>{});
+    else if (slots <= 4) batch(base, std::integral_constant<int, 4>{});
+    else if (U > 8 && slots <= 8) batch(base, std::integral_constant<int, 8>{});
+    else batch(base, std::integral_constant<int, U>{});
   }
-  // fold the PP row slots of a wave, then the waves through LDS
+  if (owner && wave == ATT_NW - 1) {  // the new position, from LDS (the last wave has the fewest cache rows)
+    f32x4 kk[1], vv[1];
+    bool valid[1];
+    kk[0] = *reinterpret_cast<const f32x4*>(kr + 4 * ln);
+    vv[0] = *reinterpret_cast<const f32x4*>(vr + 4 * ln);
+    valid[0] = sub == 0;
+    fold(kk, vv, valid, std::integral_constant<int, 1>{});
+  }
+  // fold the PP lane groups of a wave (shuffles), then the waves (LDS)
 #pragma unroll
   for (int g = 0; g < G; ++g) {
 #pragma unroll
     for (int o = 32; o >= LP; o >>= 1) {
-      acc[g][0] += __shfl_xor(acc[g][0], o);
-      acc[g][1] += __shfl_xor(acc[g][1], o);
-      acc[g][2] += __shfl_xor(acc[g][2], o);
-      acc[g][3] += __shfl_xor(acc[g][3], o);
-    }
-    if (sub == 0) *reinterpret_cast<f32x4*>(part + (size_t)(wave * G + g) * HD + 4 * ln) = acc[g];
-  }
-  __syncthreads();
-
-  // ---- phase 4: result or partial + last-arriver combine -------------------------------------------------------------
-  const int NS = a.nsplit_max;
-  constexpr int REC = HD + 2;  // partial record: out[HD], max, sum
-  float* rec0 = a.ws + ((size_t)kvh * NS) * G * REC;
-  for (int i = tid; i < G * HD; i += ATT_THREADS) {
-    const int g = i / HD, d = i % HD;
-    float o = 0.f;
+      const float mo = __shfl_xor(m[g], o);
+      const float mn = fmaxf(m[g], mo);
+      const float c = safe_exp_diff(m[g], mn), co = safe_exp_diff(mo, mn);
+      l[g] = l[g] * c + __shfl_xor(l[g], o) * co;
 #pragma unroll
-    for (int w = 0; w < ATT_NW; ++w) o += part[(size_t)(w * G + g) * HD + d];
-    if (active == 1) {
-      a.out[(size_t)(kvh * G + g) * HD + d] = o * (1.0f / (red[8 + g] + 1e-9f));  // utils.cpp:692
-    } else {
-      float* rec = rec0 + ((size_t)split * G + g) * REC;
-      rec[d] = o;
-      if (d == 0) {
-        rec[HD] = red[g];
-        rec[HD + 1] = red[8 + g];
+      for (int e = 0; e < 4; ++e) acc[g][e] = acc[g][e] * c + __shfl_xor(acc[g][e], o) * co;
+      m[g] = mn;
+    }
+    if (sub == 0) {
+      float* rec = part + (size_t)(wave * G + g) * RECL;
+      *reinterpret_cast<f32x4*>(rec + 4 * ln) = acc[g];
+      if (ln == 0) {
+        rec[HD] = m[g];
+        rec[HD + 1] = l[g];
       }
     }
   }
-  if (active == 1) return;
-  // publish: every storing wave drains its stores, the workgroup meets, ONE lane releases at agent scope and arrives
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int old = __hip_atomic_fetch_add(a.counters + kvh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = old == active - 1;
-    if (last) {
-      __hip_atomic_store(a.counters + kvh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (tid < G) {  // split-wide max and sum per head
+    float M = -INFINITY;
+    for (int w = 0; w < ATT_NW; ++w) M = fmaxf(M, part[(size_t)(w * G + tid) * RECL + HD]);
+    float L = 0.f;
+    for (int w = 0; w < ATT_NW; ++w) {
+      const float* rec = part + (size_t)(w * G + tid) * RECL;
+      L += rec[HD + 1] * safe_exp_diff(rec[HD], M);
     }
-    red[32] = __int_as_float(last);
+    red[tid] = M;
+    red[8 + tid] = L;
   }
   __syncthreads();
-  if (__float_as_int(red[32]) == 0) return;
-  // the last arriver of this kv head: combine the `active` partials in split order
+
+  // ---- phase 2: the split's partial per head: ws[head][split] = {out[HD] (unnormalised), max, sum} -----------------
   for (int i = tid; i < G * HD; i += ATT_THREADS) {
     const int g = i / HD, d = i % HD;
-    float M = -INFINITY;
-    for (int s = 0; s < active; ++s) M = fmaxf(M, rec0[((size_t)s * G + g) * REC + HD]);
-    float L = 0.f, O = 0.f;
-    for (int s = 0; s < active; ++s) {
-      const float* rec = rec0 + ((size_t)s * G + g) * REC;
-      const float w = expf(rec[HD] - M);
-      L = fmaf(rec[HD + 1], w, L);
-      O = fmaf(rec[d], w, O);
+    const float M = red[g];
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < ATT_NW; ++w) {
+      const float* rec = part + (size_t)(w * G + g) * RECL;
+      o += rec[d] * safe_exp_diff(rec[HD], M);
     }
-    a.out[(size_t)(kvh * G + g) * HD + d] = O * (1.0f / (L + 1e-9f));
+    float* rec = a.ws + ((size_t)(kvh * G + g) * TL_ATTN_MAX_SPLITS + split) * RECL;
+    rec[d] = o;
+    if (d == 0) {
+      rec[HD] = M;
+      rec[HD + 1] = red[8 + g];
+    }
   }
+}
+
+// out[h][:] = sum_s o_s e^(m_s - M) / (sum_s l_s e^(m_s - M) + 1e-9): one workgroup per head (operator-level API)
+__global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ out, int hd,
+                                                           int seq_len, const int* __restrict__ pos_dev) {
+  const int len = pos_dev ? *pos_dev + 1 : seq_len;
+  const int SL = tl_attn_split_len(len);
+  const int active = (len + SL - 1) / SL;
+  const int h = blockIdx.x, d = threadIdx.x;
+  if (d >= hd) return;
+  const int recl = hd + 4;
+  const float* rec0 = ws + (size_t)h * TL_ATTN_MAX_SPLITS * recl;
+  float M = -INFINITY;
+  for (int s = 0; s < active; ++s) M = fmaxf(M, rec0[(size_t)s * recl + hd]);
+  float L = 0.f, O = 0.f;
+  for (int s = 0; s < active; ++s) {
+    const float* rec = rec0 + (size_t)s * recl;
+    const float w = expf(rec[hd] - M);
+    L = fmaf(rec[hd + 1], w, L);
+    O = fmaf(rec[d], w, O);
+  }
+  out[(size_t)h * hd + d] = O * (1.0f / (L + 1e-9f));  // utils.cpp:692
 }
 
 template <int HD, int G>
 int launch_hg(const AttnArgs& a, bool fuse, hipStream_t s) {
-  const size_t lds = sizeof(float) * ((size_t)G * HD + 2 * HD + 64 + (size_t)G * a.split_len + (size_t)ATT_NW * G * HD);
-  TL_REQUIRE(lds <= 160 * 1024, "attention: split length %d needs %zu B of LDS", a.split_len, lds);
-  const dim3 grid(a.nkv, a.nsplit_max);
+  const size_t lds = sizeof(float) * ((size_t)G * HD + 2 * HD + 64 + (size_t)ATT_NW * G * (HD + 4));
+  const dim3 grid(a.nkv, TL_ATTN_MAX_SPLITS);
   if (fuse) {
     static bool attr = false;
     if (!attr) {
@@ -311,23 +299,19 @@ bool tl_attn_split_supported(int nh, int nkv, int hd) {
   return (hd == 64 || hd == 128) && (G == 1 || G == 2 || G == 3 || G == 4 || G == 8);
 }
 
-void tl_attn_geometry(int max_seq, int nkv, int* split_len, int* nsplit) {
-  // kv_heads x splits ~ 256 workgroups at the longest context; a split is 64..1024 positions (power of two)
-  long want = ((long)max_seq * nkv + 255) / 256;
-  int sl = 64;
-  while (sl < want && sl < 1024) sl <<= 1;
-  *split_len = sl;
-  *nsplit = (max_seq + sl - 1) / sl;
-}
+size_t tl_attn_ws_floats(int nh, int hd) { return (size_t)nh * TL_ATTN_MAX_SPLITS * (hd + 4); }
 
-size_t tl_attn_ws_floats(int nh, int hd, int nsplit) { return (size_t)nh * nsplit * (hd + 2); }
-
+// the split kernel alone: leaves partials in a.ws (combined by the consumer)
 int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s) {
   TL_REQUIRE(tl_attn_split_supported(a.nh, a.nkv, a.hd), "attention: unsupported head configuration %d/%d/%d", a.nh,
              a.nkv, a.hd);
-  TL_REQUIRE(a.ws && a.counters && a.split_len > 0 && a.nsplit_max > 0, "attention: workspace missing");
-  TL_REQUIRE((size_t)a.split_len * a.nsplit_max >= (size_t)(a.pos_dev ? a.max_seq : a.seq_len),
-             "attention: %d splits of %d positions do not cover the sequence", a.nsplit_max, a.split_len);
+  TL_REQUIRE(a.ws, "attention: workspace missing");
   const int G = a.nh / a.nkv;
   return a.hd == 64 ? launch_h<64>(a, G, fuse, s) : launch_h<128>(a, G, fuse, s);
+}
+
+int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s) {
+  attn_combine_kernel<<<a.nh, 128, 0, s>>>(a.ws, a.out, a.hd, a.seq_len, a.pos_dev);
+  TL_HIP(hipGetLastError());
+  return 0;
 }

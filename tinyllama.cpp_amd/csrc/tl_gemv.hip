@@ -222,6 +222,10 @@ struct GemvVec {
   float eps;
   int cols;
   unsigned long long* stamps;  // diagnostic instantiation only: 8 shader-clock stamps per wave
+  // GEMV_ATTN_OUT_COMBINE: x is the attention output still in split partials (tl_attn.hip), combined while staging
+  const float* attn_ws;
+  const int* attn_pos;
+  int attn_hd;
 };
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
@@ -230,11 +234,60 @@ struct GemvVec {
 struct XRegs {
   f32x4 v[4];  // the first four float4 of a thread (covers cols <= 16 * blockDim)
   f32x4 g[2];  // norm weights of the first two (norm launches have cols = hidden_size <= 8 * blockDim in practice)
+  // XATTN: the first XA_CHUNK split partials of the thread's first float4: out, (max, sum); and the active split count
+  f32x4 ao[6];
+  float am[6], al[6];
+  int active;
 };
+
+constexpr int XA_CHUNK = 6;
+// issue the loads of splits [s0, s0 + XA_CHUNK) (clamped to the active ones) of float4 index i
+__device__ __forceinline__ void xattn_issue(const GemvVec& a, int i, int s0, int active, f32x4* ao, float* am, float* al) {
+  const int hd = a.attn_hd, recl = hd + 4;
+  const int e = i << 2, h = e / hd, d = e - h * hd;
+  const float* rec0 = a.attn_ws + (size_t)h * TL_ATTN_MAX_SPLITS * recl;
+#pragma unroll
+  for (int k = 0; k < XA_CHUNK; ++k) {
+    const int s = s0 + k < active ? s0 + k : active - 1;  // unconditional loads (counted waits), clamped
+    const float* rec = rec0 + (size_t)s * recl;
+    ao[k] = *reinterpret_cast<const f32x4*>(rec + d);
+    am[k] = rec[hd];
+    al[k] = rec[hd + 1];
+  }
+}
+// fold a chunk into the running (M, L, O) of a float4
+__device__ __forceinline__ void xattn_fold(int s0, int active, const f32x4* ao, const float* am, const float* al, float& M,
+                                           float& L, f32x4& O) {
+  float mx = M;
+#pragma unroll
+  for (int k = 0; k < XA_CHUNK; ++k) mx = fmaxf(mx, s0 + k < active ? am[k] : -INFINITY);
+  const float corr = M == -INFINITY ? 0.f : expf(M - mx);
+  L *= corr;
+  O[0] *= corr; O[1] *= corr; O[2] *= corr; O[3] *= corr;
+#pragma unroll
+  for (int k = 0; k < XA_CHUNK; ++k) {
+    const float w = s0 + k < active ? expf(am[k] - mx) : 0.f;
+    L = fmaf(al[k], w, L);
+    O[0] = fmaf(ao[k][0], w, O[0]); O[1] = fmaf(ao[k][1], w, O[1]);
+    O[2] = fmaf(ao[k][2], w, O[2]); O[3] = fmaf(ao[k][3], w, O[3]);
+  }
+  M = mx;
+}
 // Unconditional (index-clamped) loads: a load under a branch makes the compiler wait with vmcnt(0) at the join,
 // which would also wait for the weight loads issued after these.
+template <bool XATTN>
 __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
   const int n4 = a.cols >> 2;
+  if (XATTN) {
+    int pos;  // scalar load: its own counter, so the partial loads below need not wait behind anything
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.attn_pos) : "memory");
+    const int len = pos + 1;
+    const int sl = tl_attn_split_len(len);
+    r.active = (len + sl - 1) / sl;
+    const int i = threadIdx.x < (unsigned)n4 ? threadIdx.x : n4 - 1;
+    xattn_issue(a, i, 0, r.active, r.ao, r.am, r.al);
+    return;
+  }
   const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
   const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
 #pragma unroll
@@ -249,10 +302,43 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
   }
 }
 __device__ __forceinline__ float ssq4(f32x4 t) { return (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]); }
+template <bool XATTN>
 __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r, float* smem) {
   float* xs = smem + XS_SCRATCH;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int n4 = a.cols >> 2;
+  if (XATTN) {
+    // x = combined attention output: out = sum_s o_s e^(m_s - M) / (sum_s l_s e^(m_s - M) + 1e-9), utils.cpp:692
+    for (int i = tid; i < n4; i += nthr) {
+      float M = -INFINITY, L = 0.f;
+      f32x4 O = {0.f, 0.f, 0.f, 0.f};
+      if (i == tid) {
+        xattn_fold(0, r.active, r.ao, r.am, r.al, M, L, O);
+      } else {
+        f32x4 ao[XA_CHUNK];
+        float am[XA_CHUNK], al[XA_CHUNK];
+        xattn_issue(a, i, 0, r.active, ao, am, al);
+        xattn_fold(0, r.active, ao, am, al, M, L, O);
+      }
+      for (int s0 = XA_CHUNK; s0 < r.active; s0 += XA_CHUNK) {
+        f32x4 ao[XA_CHUNK];
+        float am[XA_CHUNK], al[XA_CHUNK];
+        xattn_issue(a, i, s0, r.active, ao, am, al);
+        xattn_fold(s0, r.active, ao, am, al, M, L, O);
+      }
+      const float inv = 1.0f / (L + 1e-9f);
+      f32x4 t = {O[0] * inv, O[1] * inv, O[2] * inv, O[3] * inv};
+      const int idx = i << 2;
+      float* dst = xs + (idx >> 5) * XS_STRIDE;
+      *reinterpret_cast<f32x4*>(dst + (idx & 31)) = t;
+      float sm4 = (t[0] + t[1]) + (t[2] + t[3]);
+      sm4 += __shfl_xor(sm4, 1);
+      sm4 += __shfl_xor(sm4, 2);
+      if ((i & 3) == 0) dst[32 + ((i >> 2) & 1)] = sm4;
+    }
+    __syncthreads();
+    return;
+  }
   const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
   const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w);
   float nf = 1.0f;
@@ -353,7 +439,7 @@ struct StepMeta {
 // vmcnt that leaves the prefetch in flight.
 // RESID: out[r] = resid[r] + y[r]. The two residual values are loaded at ISSUE time, ahead of the step's weight loads:
 // loads complete in order, so a load in the epilogue would drain the whole prefetch queue once per row group.
-template <int TYPE, bool PAIR, bool RESID, bool STAMP>
+template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP>
 __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const XRegs& xr, float* smem, int first,
                                           int stride, int total, int lane, unsigned long long* ts) {
   const float* xs = smem + XS_SCRATCH;
@@ -361,7 +447,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   const int nspans = (nchunks + 63) >> 6;
   if (first >= total) {  // a wave without work only helps staging x
     if (STAMP) ts[1] = __builtin_readcyclecounter();
-    stage_x_finish(a, xr, smem);
+    stage_x_finish<XATTN>(a, xr, smem);
     if (STAMP) ts[2] = __builtin_readcyclecounter();
     return;
   }
@@ -430,7 +516,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   StepMeta mc, mn;
   issue(cur, mc);  // the first step's loads go out before x is staged: the HBM round trip overlaps the prologue
   if (STAMP) ts[1] = __builtin_readcyclecounter();
-  stage_x_finish(a, xr, smem);
+  stage_x_finish<XATTN>(a, xr, smem);
   if (STAMP) ts[2] = __builtin_readcyclecounter();
   while (irg < total) {
     issue(nxt, mn);
@@ -449,29 +535,41 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
 template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
 __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
                                                                 int t0, int t1, int t2, int nsegA, int wavesA) {
-  constexpr bool RESID = ROLE == GEMV_ATTN_OUT || ROLE == GEMV_DOWN;  // the roles launched with a residual
+  // the roles launched with a residual / with x still in attention partials
+  constexpr bool RESID = ROLE == GEMV_ATTN_OUT || ROLE == GEMV_DOWN || ROLE == GEMV_ATTN_OUT_COMBINE;
+  constexpr bool XATTN = ROLE == GEMV_ATTN_OUT_COMBINE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long ts[5] = {0, 0, 0, 0, 0}, rt0 = 0;
   if (STAMP) {
     ts[0] = __builtin_readcyclecounter();
     rt0 = __builtin_amdgcn_s_memrealtime();
   }
+  // All kernel arguments into SGPRs with ONE batch of scalar loads: left alone, hipcc loads them where first used,
+  // in four dependent round trips to a cold scalar cache (~2000 cycles before a wave's first weight load goes out).
+  asm volatile("" ::"s"(sg0.w.p0), "s"(sg0.w.p1), "s"(sg0.w.p2), "s"(sg0.w.p3), "s"(sg0.w.rows), "s"(sg0.out),
+               "s"(a.x), "s"(a.norm_w), "s"(a.resid), "s"(a.eps), "s"(a.cols), "s"(t0), "s"(t1), "s"(t2),
+               "s"(nsegA), "s"(wavesA));
+  if (ROLE == GEMV_ATTN_OUT_COMBINE) asm volatile("" ::"s"(a.attn_ws), "s"(a.attn_pos), "s"(a.attn_hd));
+  if (PAIR || ROLE == GEMV_QKV)
+    asm volatile("" ::"s"(sg1.w.p0), "s"(sg1.w.p1), "s"(sg1.w.p2), "s"(sg1.w.p3), "s"(sg1.w.rows), "s"(sg1.out));
+  if (ROLE == GEMV_QKV)
+    asm volatile("" ::"s"(sg2.w.p0), "s"(sg2.w.p1), "s"(sg2.w.p2), "s"(sg2.w.p3), "s"(sg2.w.rows), "s"(sg2.out));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   XRegs xr;
-  stage_x_issue(a, xr);
+  stage_x_issue<XATTN>(a, xr);
   if (TB == TL_NONE || wave < wavesA) {
     const int wA = TB == TL_NONE ? nwaves : wavesA;
     const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
     const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, t0, nsegA >= 2 ? t1 : 0x3fffffff};
-    run_class<TA, PAIR, RESID, STAMP>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane, ts);
+    run_class<TA, PAIR, RESID, XATTN, STAMP>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane, ts);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
     const int tb = nsegA == 1 ? t1 : t2;
     const Segs g = {sb.w, sb.w, sb.w, sb.out, sb.out, sb.out, 0x3fffffff, 0x3fffffff};
-    run_class<TBB, false, false, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
+    run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
                                  gridDim.x * (nwaves - wavesA), tb, lane, ts);
   }
   if (STAMP && lane == 0 && ts[3] != 0) {
@@ -608,7 +706,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
-  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr};
+  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd};
   for (int i = 0; i < 3; ++i) L.seg[i] = a.seg[i < a.nseg ? i : 0];
   const int ta = a.seg[0].w.type;
 
@@ -681,7 +779,14 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   int role = a.role;  // the residual epilogue is compiled into the ATTN_OUT / DOWN instantiations only
   if (a.resid && role != GEMV_ATTN_OUT && role != GEMV_DOWN) role = GEMV_ATTN_OUT;
   if (!a.resid && (role == GEMV_ATTN_OUT || role == GEMV_DOWN)) role = GEMV_GENERIC;
+  if (a.attn_ws) {
+    TL_REQUIRE(a.resid && a.attn_pos && !a.norm_w && a.nseg == 1 && a.attn_hd > 0 && a.attn_hd % 4 == 0 &&
+                   a.cols % a.attn_hd == 0,
+               "gemv: attention-partials input needs a single residual launch without norm");
+    role = GEMV_ATTN_OUT_COMBINE;
+  }
   switch (role) {
+    case GEMV_ATTN_OUT_COMBINE: rc = gemv_launch_type<GEMV_ATTN_OUT_COMBINE>(ta, L, s); break;
     case GEMV_QKV: rc = gemv_launch_type<GEMV_QKV>(ta, L, s); break;
     case GEMV_ATTN_OUT: rc = gemv_launch_type<GEMV_ATTN_OUT>(ta, L, s); break;
     case GEMV_DOWN: rc = gemv_launch_type<GEMV_DOWN>(ta, L, s); break;
@@ -706,7 +811,7 @@ extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, flo
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(w->cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "tl_debug_gemv_stamps: cols %d too large", w->cols);
-  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev};
+  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0};
   for (int i = 0; i < 3; ++i) L.seg[i] = GemvSeg{qw_view(w), y_dev};
   L.t[0] = (w->rows + 1) / 2;
   L.nsegA = 1;

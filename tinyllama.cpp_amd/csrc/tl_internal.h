@@ -70,7 +70,7 @@ int tl_qweight_build(int type, const void* host_blocks, int rows, int cols, tl_q
 // ---- launchers shared between the operator-level C-ABI and the model engine ---------------------------
 // GEMV over 1..3 matrices that share the input vector (q|k|v in one launch), with optional fused
 // RMSNorm prologue, residual epilogue, or gate/up SwiGLU pairing; see tl_gemv.hip
-enum GemvRole { GEMV_GENERIC = 0, GEMV_QKV, GEMV_ATTN_OUT, GEMV_GATE_UP, GEMV_DOWN, GEMV_LM_HEAD };
+enum GemvRole { GEMV_GENERIC = 0, GEMV_QKV, GEMV_ATTN_OUT, GEMV_GATE_UP, GEMV_DOWN, GEMV_LM_HEAD, GEMV_ATTN_OUT_COMBINE };
 struct GemvSeg {
   QW w;
   float* out;
@@ -84,6 +84,11 @@ struct GemvArgs {
   const float* norm_w;  // != NULL: x := rmsnorm_vector(x, norm_w, eps) first (utils.cpp:648-673)
   float eps;
   const float* resid;   // != NULL: out0[r] = resid[r] + y[r]   (single segment only)
+  // != NULL: x is the attention output still in split partials (AttnArgs::ws); the staging pass combines them.
+  // x is then ignored; cols = attn_nh * attn_hd.
+  const float* attn_ws;
+  const int* attn_pos;  // device position (sequence length - 1)
+  int attn_hd;
   int role;             // GemvRole: selects a separately named instantiation (profiling only)
 };
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
@@ -97,6 +102,13 @@ int tl_launch_rope_kv(float* q, float* k, const float* v, float* kcache, float* 
 int tl_launch_attn_decode(const float* q, const float* kc, const float* vc, float* out, int nh, int nkv, int hd,
                           int seq_len, const int* pos_dev, int max_seq, float scale, hipStream_t s);
 // split decode attention (tl_attn.hip)
+constexpr int TL_ATTN_MAX_SPLITS = 32;
+// positions per split for a sequence of `len` positions: max(32, pow2ceil(len / 32)) -> at most 32 splits
+__host__ __device__ inline int tl_attn_split_len(int len) {
+  int sl = 32;
+  while (sl * TL_ATTN_MAX_SPLITS < len) sl <<= 1;
+  return sl;
+}
 struct AttnArgs {
   const float* q;        // [nh][hd]; FUSE: un-rotated (rotated into LDS only)
   const float* k;        // FUSE only: un-rotated k [nkv][hd] of the new position
@@ -104,20 +116,18 @@ struct AttnArgs {
   float* kc;             // K cache [max_seq][nkv][hd] (FUSE: position pos is written)
   float* vc;             // V cache
   const float* table;    // FUSE only: RoPE table [max_seq][hd/2][2]
-  float* out;            // [nh][hd]
-  float* ws;             // partials: tl_attn_ws_floats(nh, hd, nsplit_max) floats
-  int* counters;         // [nkv] arrival counters, zero between launches
+  float* out;            // [nh][hd] (combine only)
+  float* ws;             // partials [nh][TL_ATTN_MAX_SPLITS][hd + 4]: out[hd] unnormalised, max, sum, pad
   int nh, nkv, hd;
   int seq_len;           // positions 0..seq_len-1 when pos_dev == NULL
   const int* pos_dev;    // != NULL: the new position lives on the device (graph replay); seq_len = *pos_dev + 1
   int max_seq;
   float scale;
-  int split_len, nsplit_max;
 };
 bool tl_attn_split_supported(int nh, int nkv, int hd);
-void tl_attn_geometry(int max_seq, int nkv, int* split_len, int* nsplit);
-size_t tl_attn_ws_floats(int nh, int hd, int nsplit);
+size_t tl_attn_ws_floats(int nh, int hd);
 int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s);
+int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s);
 
 int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, const int* n_hist_dev, float penalty,
                      hipStream_t s);

@@ -11,6 +11,7 @@
 //     device-side state block that the last kernel of a step updates, so the graph is replayed back-to-back with
 //     no host round trip, no per-token D2H of logits and no graph update (the reference syncs the stream and copies
 //     vocab*4 bytes to the host every token, model.cpp:1085-1088).
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -48,9 +49,9 @@ struct tl_model {
   // workspaces
   float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *h = nullptr, *logits = nullptr;
   float* rope = nullptr;
+  float* cand_v = nullptr;     // per-slice arg-max candidates (sampling)
+  int* cand_i = nullptr;
   float* attn_ws = nullptr;    // split-attention partials
-  int* attn_counters = nullptr;
-  int attn_split_len = 0, attn_nsplit = 0;
   bool attn_split = false;
   int* state = nullptr;  // DevState header + history ring
   int hist_cap = 0;
@@ -58,6 +59,7 @@ struct tl_model {
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
   bool finalized = false;
+  bool no_graph = false;  // TL_NO_GRAPH=1: replay steps eagerly (profilers that cannot follow graph launches)
   double weight_bytes = 0.0;  // algorithmic (GGUF) bytes of all per-token matrices incl. one embedding row
   float* kc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems; }
   float* vc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems + kv_layer_elems; }
@@ -119,8 +121,9 @@ extern "C" int tl_model_free(tl_model* m) {
   float* bufs[] = {m->out_norm, m->kv_base, m->x, m->q, m->k, m->v, m->att, m->h, m->logits, m->rope};
   for (float* b : bufs) hipFree(b);
   hipFree(m->state);
+  hipFree(m->cand_v);
+  hipFree(m->cand_i);
   hipFree(m->attn_ws);
-  hipFree(m->attn_counters);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -174,59 +177,114 @@ static double gguf_bytes(const tl_qweight* w, int rows) {
 }
 
 // ---- the per-step state + final kernel ------------------------------------------------------------------
-// penalty (api.cpp:86-97) + first-max arg-max (api.cpp:79,135) + advance of the device-side state
-__global__ __launch_bounds__(1024) void sample_advance_kernel(float* __restrict__ logits, int n, int* __restrict__ state,
+// Sampling is two launches: (1) argmax_slices_kernel: ARGMAX_SLICES workgroups each find the first maximum of one slice
+// of the raw logits; (2) sample_advance_kernel (one workgroup): applies the repetition penalty (api.cpp:86-97, in
+// order, once per occurrence) to the <= 64 penalised logits in memory, then takes the first maximum (api.cpp:79,135)
+// over {slice winners} U {penalised ids}. The penalty only ever lowers a logit, so the only way a slice winner can be
+// wrong is when it is itself a penalised id: such a slice is rescanned in full (rare, <= 64 slices).
+constexpr int ARGMAX_SLICES = 256;
+constexpr int ARGMAX_THREADS = 256;
+
+__device__ __forceinline__ void better(float v, int i, float& best, int& idx) {
+  if (v > best || (v == best && i < idx)) {
+    best = v;
+    idx = i;
+  }
+}
+// workgroup-wide first-maximum; result valid in thread 0. bv/bi: >= 16 entries of LDS each
+__device__ __forceinline__ void block_argmax(float& best, int& idx, float* bv, int* bi) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(idx, o);
+    better(ov, oi, best, idx);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    bv[threadIdx.x >> 6] = best;
+    bi[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) better(bv[w], bi[w], best, idx);
+}
+
+__global__ __launch_bounds__(ARGMAX_THREADS) void argmax_slices_kernel(const float* __restrict__ logits, int n,
+                                                                       float* __restrict__ cand_v,
+                                                                       int* __restrict__ cand_i) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int per = (n + ARGMAX_SLICES - 1) / ARGMAX_SLICES;
+  const int lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = lo + threadIdx.x; i < hi; i += ARGMAX_THREADS) {
+    const float v = logits[i];
+    if (v > best) {  // strictly greater keeps the first maximum within a thread's stride
+      best = v;
+      idx = i;
+    }
+  }
+  block_argmax(best, idx, bv, bi);
+  if (threadIdx.x == 0) {
+    cand_v[blockIdx.x] = best;
+    cand_i[blockIdx.x] = idx;
+  }
+}
+
+__global__ __launch_bounds__(1024) void sample_advance_kernel(float* __restrict__ logits, int n,
+                                                              const float* __restrict__ cand_v,
+                                                              const int* __restrict__ cand_i, int* __restrict__ state,
                                                               int hist_cap) {
   __shared__ float bv[16];
   __shared__ int bi[16];
+  __shared__ int win[64];
+  __shared__ int nwin;
   int* hist = state + kStateHeaderInts;
   const int n_hist = state[2];
   const float penalty = __int_as_float(state[3]);
-  if (penalty > 1.0f) {
-    if (threadIdx.x == 0) {
+  const int per = (n + ARGMAX_SLICES - 1) / ARGMAX_SLICES;
+  if (threadIdx.x == 0) {
+    int k = 0;
+    if (penalty > 1.0f) {  // sequential on purpose: a repeated id is penalised once per occurrence, in order
       const int start = n_hist > 64 ? n_hist - 64 : 0;
       for (int i = start; i < n_hist; ++i) {
         const int id = hist[i];
         if (id < 0 || id >= n) continue;
         const float l = logits[id];
         logits[id] = (l > 0.0f) ? l / penalty : l * penalty;
+        win[k++] = id;
       }
     }
-    __syncthreads();
-  }
-  float best = -INFINITY;
-  int idx = 0x7fffffff;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float v = logits[i];
-    if (v > best) {
-      best = v;
-      idx = i;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    const float ov = __shfl_xor(best, o);
-    const int oi = __shfl_xor(idx, o);
-    if (ov > best || (ov == best && oi < idx)) {
-      best = ov;
-      idx = oi;
-    }
-  }
-  if ((threadIdx.x & 63) == 0) {
-    bv[threadIdx.x >> 6] = best;
-    bi[threadIdx.x >> 6] = idx;
+    nwin = k;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) {
-        best = bv[w];
-        idx = bi[w];
+  const int nw = nwin;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int s = threadIdx.x; s < ARGMAX_SLICES; s += blockDim.x) {
+    const int ci = cand_i[s];
+    bool penalised = false;
+    for (int k = 0; k < nw; ++k) penalised |= win[k] == ci;
+    if (!penalised) {
+      if (ci != 0x7fffffff) better(cand_v[s], ci, best, idx);
+    } else {  // the slice winner was lowered: rescan the slice (now holding the penalised values)
+      const int lo = s * per, hi = lo + per < n ? lo + per : n;
+      for (int i = lo; i < hi; ++i) {
+        const float v = logits[i];
+        if (v > best || (v == best && i < idx)) {
+          best = v;
+          idx = i;
+        }
       }
-    if (idx == 0x7fffffff) idx = 0;
-    state[0] = idx;                            // next input token
-    state[1] = state[1] + 1;                   // next position
-    if (n_hist < hist_cap) hist[n_hist] = idx; // generated ids, in order
+    }
+  }
+  block_argmax(best, idx, bv, bi);
+  if (threadIdx.x == 0) {
+    if (idx == 0x7fffffff) idx = 0;             // all -inf/NaN: std::max_element returns the first element
+    state[0] = idx;                             // next input token
+    state[1] = state[1] + 1;                    // next position
+    if (n_hist < hist_cap) hist[n_hist] = idx;  // generated ids, in order
     state[2] = n_hist + 1;
   }
 }
@@ -280,15 +338,12 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
       t.table = m->rope;
       t.out = m->att;
       t.ws = m->attn_ws;
-      t.counters = m->attn_counters;
       t.nh = c.num_attention_heads;
       t.nkv = c.num_key_value_heads;
       t.hd = m->head_dim;
       t.pos_dev = pos_dev;
       t.max_seq = c.max_position_embeddings;
       t.scale = scale;
-      t.split_len = m->attn_split_len;
-      t.nsplit_max = m->attn_nsplit;
       PROF_MARK(2);
       TL_TRY(tl_launch_attn_split(t, true, s));
     } else {
@@ -304,6 +359,11 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
     o.nseg = 1;
     o.cols = c.hidden_size;
     o.x = m->att;
+    if (m->attn_split) {  // the attention output is still in split partials: combined while staging x
+      o.attn_ws = m->attn_ws;
+      o.attn_pos = pos_dev;
+      o.attn_hd = m->head_dim;
+    }
     o.resid = m->x;
     o.role = GEMV_ATTN_OUT;
     TL_TRY(tl_launch_gemv(o, s));
@@ -340,7 +400,8 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
   f.role = GEMV_LM_HEAD;
   TL_TRY(tl_launch_gemv(f, s));
   PROF_MARK(7);
-  sample_advance_kernel<<<1, 1024, 0, s>>>(m->logits, c.vocab_size, m->state, m->hist_cap);
+  argmax_slices_kernel<<<ARGMAX_SLICES, ARGMAX_THREADS, 0, s>>>(m->logits, c.vocab_size, m->cand_v, m->cand_i);
+  sample_advance_kernel<<<1, 256, 0, s>>>(m->logits, c.vocab_size, m->cand_v, m->cand_i, m->state, m->hist_cap);
   TL_HIP(hipGetLastError());
   PROF_MARK(8);
   return 0;
@@ -386,13 +447,11 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->logits, sizeof(float) * V));
   TL_HIP(hipMalloc(&m->rope, sizeof(float) * P * m->head_dim));
   TL_TRY(tl_rope_table_upload(m->rope, (int)P, m->head_dim, c.rope_theta, m->stream));
+  TL_HIP(hipMalloc(&m->cand_v, sizeof(float) * ARGMAX_SLICES));
+  TL_HIP(hipMalloc(&m->cand_i, sizeof(int) * ARGMAX_SLICES));
   m->attn_split = tl_attn_split_supported(c.num_attention_heads, c.num_key_value_heads, m->head_dim);
-  if (m->attn_split) {
-    tl_attn_geometry((int)P, c.num_key_value_heads, &m->attn_split_len, &m->attn_nsplit);
-    TL_HIP(hipMalloc(&m->attn_ws, sizeof(float) * tl_attn_ws_floats(c.num_attention_heads, m->head_dim, m->attn_nsplit)));
-    TL_HIP(hipMalloc(&m->attn_counters, sizeof(int) * (size_t)c.num_key_value_heads));
-    TL_HIP(hipMemsetAsync(m->attn_counters, 0, sizeof(int) * (size_t)c.num_key_value_heads, m->stream));
-  }
+  if (m->attn_split)
+    TL_HIP(hipMalloc(&m->attn_ws, sizeof(float) * tl_attn_ws_floats(c.num_attention_heads, m->head_dim)));
   m->hist_cap = (int)P + 64;
   TL_HIP(hipMalloc(&m->state, sizeof(int) * (kStateHeaderInts + m->hist_cap)));
   TL_HIP(hipMemsetAsync(m->state, 0, sizeof(int) * (kStateHeaderInts + m->hist_cap), m->stream));
@@ -400,6 +459,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));
   TL_TRY(enqueue_step(m));
   TL_HIP(hipStreamSynchronize(m->stream));
+  if (const char* e = getenv("TL_NO_GRAPH")) m->no_graph = atoi(e) != 0;
   // capture the step once
   TL_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
   int rc = enqueue_step(m);
@@ -426,7 +486,8 @@ extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits
   TL_REQUIRE(pos >= 0 && pos < m->cfg.max_position_embeddings, "tl_model_decode: pos %d outside [0,%d)", pos,
              m->cfg.max_position_embeddings);
   TL_TRY(set_state(m, token_id, pos, 1.0f, nullptr, 0));
-  TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+  if (m->no_graph) TL_TRY(enqueue_step(m));
+  else TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
   if (logits_host)
     TL_HIP(hipMemcpyAsync(logits_host, m->logits, sizeof(float) * (size_t)m->cfg.vocab_size, hipMemcpyDeviceToHost, m->stream));
   if (next_token_host) TL_HIP(hipMemcpyAsync(next_token_host, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
@@ -445,7 +506,10 @@ extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_
   const int keep = n_history > 64 ? 64 : n_history;
   TL_REQUIRE(keep + n_steps <= m->hist_cap, "tl_model_generate_greedy: %d steps exceed the id history capacity", n_steps);
   TL_TRY(set_state(m, first_token, start_pos, penalty, history_host ? history_host + (n_history - keep) : nullptr, keep));
-  for (int i = 0; i < n_steps; ++i) TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+  for (int i = 0; i < n_steps; ++i) {
+    if (m->no_graph) TL_TRY(enqueue_step(m));
+    else TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+  }
   if (n_steps > 0 && out_ids_host)
     TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
                           hipMemcpyDeviceToHost, m->stream));
@@ -473,7 +537,8 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   const size_t V = (size_t)m->cfg.vocab_size;
   for (int i = 0; rc == 0 && e == hipSuccess && i < num_tokens; ++i) {
     set_token_kernel<<<1, 1, 0, m->stream>>>(m->state, toks_dev, i);
-    e = hipGraphLaunch(m->graph_exec, m->stream);
+    if (m->no_graph) rc = enqueue_step(m);
+    else e = hipGraphLaunch(m->graph_exec, m->stream);
     if (e == hipSuccess && all_logits_host)
       e = hipMemcpyAsync(all_logits_host + (size_t)i * V, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream);
   }

@@ -310,11 +310,8 @@ extern "C" int tl_attention(const float* q_dev, const float* k_cache_dev, const 
     // operator-level calls share one lazily grown workspace per process (not for use under stream capture)
     static float* ws = nullptr;
     static size_t ws_floats = 0;
-    static int* counters = nullptr;
-    static int counters_n = 0;
     AttnArgs a = {};
-    tl_attn_geometry(current_seq_len, cache_num_kv_heads, &a.split_len, &a.nsplit_max);
-    const size_t need = tl_attn_ws_floats(num_heads, head_dim, a.nsplit_max);
+    const size_t need = tl_attn_ws_floats(num_heads, head_dim);
     if (need > ws_floats) {
       TL_HIP(hipDeviceSynchronize());
       if (ws) TL_HIP(hipFree(ws));
@@ -323,28 +320,19 @@ extern "C" int tl_attention(const float* q_dev, const float* k_cache_dev, const 
       TL_HIP(hipMalloc(&ws, need * sizeof(float)));
       ws_floats = need;
     }
-    if (cache_num_kv_heads > counters_n) {
-      TL_HIP(hipDeviceSynchronize());
-      if (counters) TL_HIP(hipFree(counters));
-      counters = nullptr;
-      counters_n = 0;
-      TL_HIP(hipMalloc(&counters, sizeof(int) * (size_t)cache_num_kv_heads));
-      TL_HIP(hipMemset(counters, 0, sizeof(int) * (size_t)cache_num_kv_heads));
-      counters_n = cache_num_kv_heads;
-    }
     a.q = q_dev;
     a.kc = const_cast<float*>(k_cache_dev);
     a.vc = const_cast<float*>(v_cache_dev);
     a.out = out_dev;
     a.ws = ws;
-    a.counters = counters;
     a.nh = num_heads;
     a.nkv = cache_num_kv_heads;
     a.hd = head_dim;
     a.seq_len = current_seq_len;
     a.max_seq = cache_max_seq_len;
     a.scale = scale;
-    return tl_launch_attn_split(a, false, static_cast<hipStream_t>(stream));
+    TL_TRY(tl_launch_attn_split(a, false, static_cast<hipStream_t>(stream)));
+    return tl_launch_attn_combine(a, static_cast<hipStream_t>(stream));
   }
   return tl_launch_attn_decode(q_dev, k_cache_dev, v_cache_dev, out_dev, num_heads, cache_num_kv_heads, head_dim,
                                current_seq_len, nullptr, cache_max_seq_len, scale, static_cast<hipStream_t>(stream));

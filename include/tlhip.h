@@ -154,6 +154,11 @@ int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int st
  * `nw` equally-shaped matrices (use more than the 256 MiB Infinity Cache holds), timed with HIP events on `stream`. */
 int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int iters, int warmup,
                     float* avg_us_out, void* stream);
+/* Measurement hook (experiment, no counterpart in the reference): the tl_bench_matvec chain captured into a two-branch
+ * graph in which a second stream pulls matrix i+1 into the Infinity Cache while the GEMV over matrix i runs
+ * (prefetch_blocks workgroups of 256 threads; 0 = no prefetch branch, same graph otherwise). */
+int tl_bench_matvec_prefetch(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int reps,
+                             int prefetch_blocks, float* avg_us_out);
 /* Diagnostic hook (no counterpart in the reference): one tl_matvec_q-shaped launch of an instrumented build of the
  * GEMV kernel; stamps_dev[8 * grid * waves] u64 receives per-wave shader-clock stamps (see tl_gemv.hip). */
 int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, unsigned long long* stamps_dev,

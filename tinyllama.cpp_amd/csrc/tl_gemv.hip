@@ -24,6 +24,8 @@
 //   - epilogues: plain store, residual add, or SwiGLU of a gate/up row pair.
 #include <stdlib.h>
 
+#include <vector>
+
 #include "tl_internal.h"
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -834,6 +836,99 @@ extern "C" int tl_matvec_q(const tl_qweight* w, const float* x_dev, float* y_dev
   a.cols = w->cols;
   a.x = x_dev;
   return tl_launch_gemv(a, static_cast<hipStream_t>(stream));
+}
+
+// ---- Infinity-Cache prefetch ------------------------------------------------------------------------------------------
+// Reads [p, p + bytes) with default-policy 16 B loads and throws the data away: the lines land in the 256 MiB
+// memory-side Infinity Cache, from where a later (non-temporal) weight stream reads them faster than from HBM. Meant
+// to run on a second stream / graph branch BESIDE the kernel that precedes the consumer of these bytes.
+__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned acc = 0;
+  for (; i + 7 * stride < n16; i += 8 * stride) {
+    u32x4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[i + k * stride];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc ^= v[k][0] ^ v[k][1] ^ v[k][2] ^ v[k][3];
+  }
+  for (; i < n16; i += stride) {
+    const u32x4 v = p[i];
+    acc ^= v[0] ^ v[1] ^ v[2] ^ v[3];
+  }
+  if (acc == 0x9e3779b9u && sink) *sink = acc;  // keeps the loads alive; practically never taken
+}
+
+int tl_launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t s) {
+  if (bytes < 16 || blocks <= 0) return 0;
+  prefetch_kernel<<<blocks, 256, 0, s>>>(reinterpret_cast<const u32x4*>(p), bytes / 16, sink);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// Measurement hook (experiment): like tl_bench_matvec, but a second stream prefetches matrix i+1 into the Infinity Cache
+// while the GEMV over matrix i runs; the whole chain is captured into one graph (two branches) and replayed.
+extern "C" int tl_bench_matvec_prefetch(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int reps,
+                                        int prefetch_blocks, float* avg_us_out) {
+  TL_REQUIRE(ws && nw > 1 && x_dev && y_dev && reps > 0 && avg_us_out, "tl_bench_matvec_prefetch: bad argument");
+  hipStream_t sa, sb;
+  TL_HIP(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking));
+  TL_HIP(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+  unsigned* sink = nullptr;
+  TL_HIP(hipMalloc(&sink, 4));
+  TL_TRY(tl_matvec_q(ws[0], x_dev, y_dev, sa));  // attributes set outside capture
+  TL_HIP(hipStreamSynchronize(sa));
+  std::vector<hipEvent_t> evs;
+  auto new_event = [&]() {
+    hipEvent_t e;
+    hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    evs.push_back(e);
+    return e;
+  };
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  TL_HIP(hipStreamBeginCapture(sa, hipStreamCaptureModeThreadLocal));
+  int rc = 0;
+  for (int i = 0; i < nw && rc == 0; ++i) {
+    if (prefetch_blocks > 0) {  // branch: prefetch of matrix i+1 starts when GEMV i-1 has finished (= GEMV i starts)
+      hipEvent_t e = new_event();
+      hipEventRecord(e, sa);
+      hipStreamWaitEvent(sb, e, 0);
+      const tl_qweight* nxt = ws[(i + 1) % nw];
+      rc = tl_launch_prefetch(nxt->base, nxt->bytes, prefetch_blocks, sink, sb);
+    }
+    if (rc == 0) rc = tl_matvec_q(ws[i], x_dev, y_dev, sa);
+  }
+  if (prefetch_blocks > 0) {  // join the branch
+    hipEvent_t e = new_event();
+    hipEventRecord(e, sb);
+    hipStreamWaitEvent(sa, e, 0);
+  }
+  hipError_t ce = hipStreamEndCapture(sa, &graph);
+  if (rc != 0) return rc;
+  TL_HIP(ce);
+  TL_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  hipEvent_t e0, e1;
+  TL_HIP(hipEventCreate(&e0));
+  TL_HIP(hipEventCreate(&e1));
+  TL_HIP(hipGraphLaunch(exec, sa));  // warm-up
+  TL_HIP(hipEventRecord(e0, sa));
+  for (int r = 0; r < reps; ++r) TL_HIP(hipGraphLaunch(exec, sa));
+  TL_HIP(hipEventRecord(e1, sa));
+  TL_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  TL_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *avg_us_out = ms * 1e3f / ((float)reps * nw);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  for (hipEvent_t e : evs) hipEventDestroy(e);
+  hipGraphExecDestroy(exec);
+  hipGraphDestroy(graph);
+  hipFree(sink);
+  hipStreamDestroy(sa);
+  hipStreamDestroy(sb);
+  return 0;
 }
 
 // Measurement hook: `iters` back-to-back GEMVs cycling through `nw` equally-shaped matrices (more than the

@@ -92,6 +92,7 @@ struct GemvArgs {
   int role;             // GemvRole: selects a separately named instantiation (profiling only)
 };
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
+int tl_launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t s);
 
 int tl_launch_rmsnorm(const float* x, const float* w, float* out, int T, int n, float eps, int floor_eps,
                       hipStream_t s);

@@ -41,8 +41,13 @@ def main():
         us = C.c_float()
         check(lib().tl_bench_matvec(arr, nw, x.ptr, y.ptr, iters, 20, C.byref(us), None), "tl_bench_matvec")
         gbps = nbytes / (us.value * 1e-6) / 1e9
-        print(f"{S.TYPE_NAMES[typ]:5s} {rows:6d} x {cols:5d}  {nbytes / 1e6:8.2f} MB  nw={nw:2d}  {us.value:8.2f} us  "
-              f"{gbps:7.1f} GB/s  {gbps / 80:5.1f}% of 8 TB/s", flush=True)
+        line = (f"{S.TYPE_NAMES[typ]:5s} {rows:6d} x {cols:5d}  {nbytes / 1e6:8.2f} MB  nw={nw:2d}  {us.value:8.2f} us  "
+                f"{gbps:7.1f} GB/s  {gbps / 80:5.1f}% of 8 TB/s")
+        if os.environ.get("TL_BENCH_PREFETCH"):  # graph replay without / with an Infinity-Cache prefetch branch
+            for pb in [0] + [int(v) for v in os.environ["TL_BENCH_PREFETCH"].split(",")]:
+                check(lib().tl_bench_matvec_prefetch(arr, nw, x.ptr, y.ptr, 5, pb, C.byref(us)), "prefetch bench")
+                line += f" | pf{pb}: {us.value:6.2f} us"
+        print(line, flush=True)
         for w in ws:
             w.free()
 

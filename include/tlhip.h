@@ -169,6 +169,10 @@ int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, 
  * 4 O GEMV+residual, 5 norm+gate/up GEMV+SwiGLU, 6 down GEMV+residual, 7 norm+lm_head GEMV, 8 sample+advance. */
 int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_steps, float* kind_ms_out,
                             int* kind_launches_out);
+/* Measurement hook (no counterpart in the reference): `iters` back-to-back launches of ONE kind of the decode step's
+ * GEMV kernels (kinds as above: 1, 4, 5, 6, 7), cycling through the layers so that every launch streams from HBM,
+ * timed with HIP events on the engine's stream. Leaves activations / logits in an unspecified state. */
+int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* avg_us_out, double* bytes_per_launch_out);
 /* device pointers into the model's state, for parity tests and for hosts that keep using the operator-level
  * calls: which = 0 K cache, 1 V cache of `layer` ([max_pos][n_kv_heads_local][head_dim] f32), 2 = x (hidden) */
 int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out);

@@ -73,6 +73,7 @@ SIGNATURES = {
     "tl_bench_matvec_prefetch": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float)],
     "tl_debug_gemv_stamps": [_vp, _fp, _fp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp],
     "tl_model_profile_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
+    "tl_model_bench_kernel": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)],
     "tl_model_device_ptr": [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "tl_model_bytes_per_token": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "tl_tp_unique_id": [_vp],

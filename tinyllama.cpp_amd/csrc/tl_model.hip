@@ -305,6 +305,72 @@ struct StepProf {
 };
 #define PROF_MARK(k) do { if (prof) TL_TRY(prof->mark(s, (k))); } while (0)
 
+// ---- the GEMV launches of a step (also used one kind at a time by tl_model_bench_kernel) ---------------------------
+static GemvArgs args_qkv(tl_model* m, int l) {
+  LayerW& L = m->layers[l];
+  GemvArgs a = {};
+  a.seg[0] = {qw_view(L.q[TL_T_ATTN_Q]), m->q};
+  a.seg[1] = {qw_view(L.q[TL_T_ATTN_K]), m->k};
+  a.seg[2] = {qw_view(L.q[TL_T_ATTN_V]), m->v};
+  a.nseg = 3;
+  a.cols = m->cfg.hidden_size;
+  a.x = m->x;
+  a.norm_w = L.attn_norm;
+  a.eps = m->cfg.rms_norm_eps;
+  a.role = GEMV_QKV;
+  return a;
+}
+static GemvArgs args_attn_out(tl_model* m, int l) {
+  GemvArgs o = {};
+  o.seg[0] = {qw_view(m->layers[l].q[TL_T_ATTN_OUTPUT]), m->x};
+  o.nseg = 1;
+  o.cols = m->cfg.hidden_size;
+  o.x = m->att;
+  if (m->attn_split) {  // the attention output is still in split partials: combined while staging x
+    o.attn_ws = m->attn_ws;
+    o.attn_pos = m->state + 1;
+    o.attn_hd = m->head_dim;
+  }
+  o.resid = m->x;
+  o.role = GEMV_ATTN_OUT;
+  return o;
+}
+static GemvArgs args_gate_up(tl_model* m, int l) {
+  LayerW& L = m->layers[l];
+  GemvArgs g = {};
+  g.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), m->h};
+  g.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), nullptr};
+  g.nseg = 2;
+  g.pair = 1;
+  g.cols = m->cfg.hidden_size;
+  g.x = m->x;
+  g.norm_w = L.ffn_norm;
+  g.eps = m->cfg.rms_norm_eps;
+  g.role = GEMV_GATE_UP;
+  return g;
+}
+static GemvArgs args_down(tl_model* m, int l) {
+  GemvArgs d = {};
+  d.seg[0] = {qw_view(m->layers[l].q[TL_T_FFN_DOWN]), m->x};
+  d.nseg = 1;
+  d.cols = m->cfg.intermediate_size;
+  d.x = m->h;
+  d.resid = m->x;
+  d.role = GEMV_DOWN;
+  return d;
+}
+static GemvArgs args_lm_head(tl_model* m) {
+  GemvArgs f = {};
+  f.seg[0] = {qw_view(m->out), m->logits};
+  f.nseg = 1;
+  f.cols = m->cfg.hidden_size;
+  f.x = m->x;
+  f.norm_w = m->out_norm;
+  f.eps = m->cfg.rms_norm_eps;
+  f.role = GEMV_LM_HEAD;
+  return f;
+}
+
 static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
   const tl_model_config& c = m->cfg;
   hipStream_t s = m->stream;
@@ -315,18 +381,7 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
   TL_TRY(tl_launch_dequant_rows(m->tok, tok_dev, 0, 1, m->x, s));
   PROF_MARK(0);
   for (int l = 0; l < c.num_hidden_layers; ++l) {
-    LayerW& L = m->layers[l];
-    GemvArgs a = {};
-    a.seg[0] = {qw_view(L.q[TL_T_ATTN_Q]), m->q};
-    a.seg[1] = {qw_view(L.q[TL_T_ATTN_K]), m->k};
-    a.seg[2] = {qw_view(L.q[TL_T_ATTN_V]), m->v};
-    a.nseg = 3;
-    a.cols = c.hidden_size;
-    a.x = m->x;
-    a.norm_w = L.attn_norm;
-    a.eps = c.rms_norm_eps;
-    a.role = GEMV_QKV;
-    TL_TRY(tl_launch_gemv(a, s));
+    TL_TRY(tl_launch_gemv(args_qkv(m, l), s));
     PROF_MARK(1);
     if (m->attn_split) {  // RoPE + KV write + split attention in one launch
       AttnArgs t = {};
@@ -354,56 +409,62 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
                                    m->head_dim, 0, pos_dev, c.max_position_embeddings, scale, s));
     }
     PROF_MARK(3);
-    GemvArgs o = {};
-    o.seg[0] = {qw_view(L.q[TL_T_ATTN_OUTPUT]), m->x};
-    o.nseg = 1;
-    o.cols = c.hidden_size;
-    o.x = m->att;
-    if (m->attn_split) {  // the attention output is still in split partials: combined while staging x
-      o.attn_ws = m->attn_ws;
-      o.attn_pos = pos_dev;
-      o.attn_hd = m->head_dim;
-    }
-    o.resid = m->x;
-    o.role = GEMV_ATTN_OUT;
-    TL_TRY(tl_launch_gemv(o, s));
+    TL_TRY(tl_launch_gemv(args_attn_out(m, l), s));
     PROF_MARK(4);
-    GemvArgs g = {};
-    g.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), m->h};
-    g.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), nullptr};
-    g.nseg = 2;
-    g.pair = 1;
-    g.cols = c.hidden_size;
-    g.x = m->x;
-    g.norm_w = L.ffn_norm;
-    g.eps = c.rms_norm_eps;
-    g.role = GEMV_GATE_UP;
-    TL_TRY(tl_launch_gemv(g, s));
+    TL_TRY(tl_launch_gemv(args_gate_up(m, l), s));
     PROF_MARK(5);
-    GemvArgs d = {};
-    d.seg[0] = {qw_view(L.q[TL_T_FFN_DOWN]), m->x};
-    d.nseg = 1;
-    d.cols = c.intermediate_size;
-    d.x = m->h;
-    d.resid = m->x;
-    d.role = GEMV_DOWN;
-    TL_TRY(tl_launch_gemv(d, s));
+    TL_TRY(tl_launch_gemv(args_down(m, l), s));
     PROF_MARK(6);
   }
-  GemvArgs f = {};
-  f.seg[0] = {qw_view(m->out), m->logits};
-  f.nseg = 1;
-  f.cols = c.hidden_size;
-  f.x = m->x;
-  f.norm_w = m->out_norm;
-  f.eps = c.rms_norm_eps;
-  f.role = GEMV_LM_HEAD;
-  TL_TRY(tl_launch_gemv(f, s));
+  TL_TRY(tl_launch_gemv(args_lm_head(m), s));
   PROF_MARK(7);
   argmax_slices_kernel<<<ARGMAX_SLICES, ARGMAX_THREADS, 0, s>>>(m->logits, c.vocab_size, m->cand_v, m->cand_i);
   sample_advance_kernel<<<1, 256, 0, s>>>(m->logits, c.vocab_size, m->cand_v, m->cand_i, m->state, m->hist_cap);
   TL_HIP(hipGetLastError());
   PROF_MARK(8);
+  return 0;
+}
+
+// Measurement hook: `iters` back-to-back launches of ONE kind of the step's GEMVs (1 QKV, 4 attn_output, 5 gate/up,
+// 6 down, 7 lm_head), cycling through the layers so that every launch streams its weights from HBM, between two HIP
+// events on the engine's stream. bytes_per_launch_out = the average GGUF bytes of the matrices one launch reads.
+extern "C" int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* avg_us_out,
+                                     double* bytes_per_launch_out) {
+  TL_REQUIRE(m && m->finalized && iters > 0 && warmup >= 0 && avg_us_out, "tl_model_bench_kernel: bad argument");
+  TL_REQUIRE(kind == 1 || kind == 4 || kind == 5 || kind == 6 || kind == 7, "tl_model_bench_kernel: kind %d", kind);
+  const int L = m->cfg.num_hidden_layers;
+  auto args_of = [&](int i) {
+    const int l = i % L;
+    switch (kind) {
+      case 1: return args_qkv(m, l);
+      case 4: return args_attn_out(m, l);
+      case 5: return args_gate_up(m, l);
+      case 6: return args_down(m, l);
+      default: return args_lm_head(m);
+    }
+  };
+  double bytes = 0.0;
+  for (int i = 0; i < iters; ++i) {
+    const GemvArgs a = args_of(i);
+    for (int k = 0; k < a.nseg; ++k)
+      bytes += (double)a.seg[k].w.rows * a.seg[k].w.cols / tl_type_block_elems(a.seg[k].w.type) *
+               (double)tl_type_block_bytes(a.seg[k].w.type);
+  }
+  hipStream_t s = m->stream;
+  hipEvent_t e0, e1;
+  TL_HIP(hipEventCreate(&e0));
+  TL_HIP(hipEventCreate(&e1));
+  for (int i = 0; i < warmup; ++i) TL_TRY(tl_launch_gemv(args_of(i), s));
+  TL_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) TL_TRY(tl_launch_gemv(args_of(i), s));
+  TL_HIP(hipEventRecord(e1, s));
+  TL_HIP(hipEventSynchronize(e1));
+  float ms = 0.f;
+  TL_HIP(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *avg_us_out = ms * 1e3f / iters;
+  if (bytes_per_launch_out) *bytes_per_launch_out = bytes / iters;
   return 0;
 }
 

@@ -120,6 +120,9 @@ def tensor_kind(name):
     return KINDS[kn], int(li)
 
 
+PROFILE_KIND_INDEX = {"qkv_gemv": 1, "attn_out_gemv": 4, "gate_up_gemv": 5, "down_gemv": 6, "lm_head_gemv": 7}
+
+
 class Model:
     """The device-resident model (tl_model): cfg is a dict with the synth.SHAPES keys."""
 
@@ -212,6 +215,13 @@ class Model:
         check(lib().tl_model_profile_decode(self.h, int(first_token), int(start_pos), int(n_steps), ms.ctypes.data,
                                             cnt.ctypes.data), "tl_model_profile_decode")
         return {k: (float(ms[i]) / max(int(cnt[i]), 1), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+
+    def bench_kernel(self, kind, iters=256, warmup=32):
+        """(avg_us_per_launch, gguf_bytes_per_launch) of one kind of the step's GEMV kernels, back to back."""
+        us, nb = C.c_float(), C.c_double()
+        check(lib().tl_model_bench_kernel(self.h, PROFILE_KIND_INDEX[kind], int(iters), int(warmup), C.byref(us),
+                                          C.byref(nb)), "tl_model_bench_kernel")
+        return us.value, nb.value
 
     def device_ptr(self, which, layer=0):
         p = C.c_void_p()

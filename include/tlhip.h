@@ -132,8 +132,10 @@ enum tl_tensor_kind {
 
 int tl_model_create(const tl_model_config* cfg, tl_model** out);
 int tl_model_free(tl_model* m);
-/* host_data: raw GGUF tensor bytes of the FULL (unsharded) tensor; with tp_size>1 the handle keeps only its
- * shard (row split for q/k/v/gate/up/output, column split for attn_output/ffn_down). layer = -1 for globals. */
+/* host_data: raw GGUF tensor bytes (blocks row-major by output row). With tp_size > 1 the caller passes THIS RANK'S SHARD
+ * with its local shape: attn_q/k/v, ffn_gate/up, output by rows (rank-th block of heads / intermediate columns / vocab
+ * rows), attn_output/ffn_down by columns (rank-th block of input columns, a multiple of 256); token_embd and the norms
+ * whole (tinyllama.cpp_amd/tp.py has the slicing). layer = -1 for globals. */
 int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, const void* host_data, int rows, int cols);
 /* allocate KV cache + workspaces, upload the RoPE table, check every tensor is present */
 int tl_model_finalize(tl_model* m);
@@ -178,10 +180,16 @@ int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* a
 int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out);
 /* algorithmic bytes one decode step at position pos must move on this rank (SURVEY §8d B_tok) */
 int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, double* kv_bytes);
-/* tensor-parallel wiring: RCCL communicator over xGMI; unique_id is ncclUniqueId bytes (128) produced by
- * tl_tp_unique_id on rank 0 and broadcast by the host (torch.distributed) */
+/* tensor-parallel wiring (one process per GPU): RCCL communicator over xGMI; unique_id is the ncclUniqueId (128 bytes)
+ * produced by tl_tp_unique_id on rank 0 and broadcast by the host (torch.distributed). Call tl_model_tp_init on every
+ * rank before tl_model_finalize: the decode step (incl. its 2 all-reduces per layer and the logits all-gather) is
+ * captured into the graph there. Replaces distributed_coordinator.cpp's MPI request routing. */
 int tl_tp_unique_id(void* id_out_128);
 int tl_model_tp_init(tl_model* m, const void* unique_id_128);
+/* Test hook: ALL n shards of a tp_size = n model live in this process on this device (created with tp_rank = 0..n-1,
+ * finalized without tl_model_tp_init); one decode step in lockstep, collectives as plain kernels. */
+int tl_tp_local_group_decode(tl_model* const* shards, int n, int token_id, int pos, float* logits_host,
+                             int* next_token_host);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,56 @@
+"""Tensor-parallel shards on ONE GPU (MI355X): all shards of a tp_size-way model live in this process and step in
+lockstep through tl_tp_local_group_decode (collectives as plain kernels). Exercises tp.py's slicing, the local shapes
+in tl_model, the partial + residual-on-rank-0 scheme, the logits all-gather placement and per-shard sampling, against
+the unsharded CPU oracle. RCCL itself only enters when the ranks are separate processes (bench.py --gpus N)."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleModel
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
+
+
+@pytest.mark.parametrize("shape,mix,tp", [("tiny-gqa", "q4_k_m", 2), ("tiny-tp", "q4_k_m", 2), ("tiny-tp", "q4_k_m", 4),
+                                          ("tiny-tp", "q6_k", 4), ("tiny-tp", "q8_0", 2)])
+def test_tp_local_group_matches_oracle(pkg, oracle, shape, mix, tp):
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model(shape, mix, seed=5)
+    shards = [E.Model(cfg, tp_rank=r, tp_size=tp).load(tensors) for r in range(tp)]
+    om = OracleModel(oracle, cfg, tensors)
+    toks = np.random.default_rng(2).integers(0, cfg["vocab"], 9).astype(np.int32)
+    om.reset_kv()
+    for pos, tok in enumerate(toks):
+        _, want = om.forward(om.lookup_embedding(int(tok)), pos)
+        logits, nxt = E.tp_local_group_decode(shards, int(tok), pos)
+        assert close(logits, want, LOGIT_TOL).all(), (pos, np.abs(logits - want).max())
+        assert nxt == int(np.argmax(want))
+    # each shard's KV cache holds its own kv heads of the oracle's cache
+    hd = cfg["hidden"] // cfg["n_heads"]
+    kvl = cfg["n_kv_heads"] // tp * hd
+    for r, m in enumerate(shards):
+        kvd = np.empty((len(toks), kvl), np.float32)
+        from tinyllama_cpp_amd.capi import check, lib
+        check(lib().tl_memcpy_d2h(kvd.ctypes.data, m.device_ptr(0, 0), kvd.nbytes, None), "d2h")
+        want_k = om.kcache(0, len(toks))[:, r * kvl:(r + 1) * kvl]
+        assert close(kvd, want_k, LOGIT_TOL).all()
+        w, _ = m.bytes_per_token(3)
+        assert w < pkg.synth.weight_bytes_per_token(cfg, mix)  # a shard reads a fraction of the bytes
+    for m in shards:
+        m.free()
+    om.close()
+
+
+def test_tp_rejects_bad_splits(pkg):
+    from tinyllama_cpp_amd import engine as E
+    cfg = dict(pkg.synth.SHAPES["tiny-gqa"])
+    with pytest.raises(ValueError):
+        E.Model(cfg, tp_rank=0, tp_size=4)  # 2 kv heads do not split 4 ways
+    with pytest.raises(ValueError):
+        E.Model(dict(pkg.synth.SHAPES["tiny"]), tp_rank=0, tp_size=2)  # 128-column shards of attn_output

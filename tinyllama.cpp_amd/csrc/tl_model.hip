@@ -16,6 +16,8 @@
 
 #include <vector>
 
+#include <rccl/rccl.h>
+
 #include "tl_internal.h"
 
 namespace {
@@ -38,7 +40,14 @@ struct LayerW {
 
 struct tl_model {
   tl_model_config cfg;
-  int head_dim = 0, kv_dim = 0;
+  int head_dim = 0, kv_dim = 0;  // kv_dim: LOCAL kv heads x head_dim
+  // tensor parallel shard (tp == 1: the whole model): local query heads / kv heads / intermediate columns / vocab rows
+  int tp = 1, rank = 0;
+  int nh_l = 0, nkv_l = 0, I_l = 0, V_l = 0, qd_l = 0;
+  float* xp = nullptr;     // tp > 1: this rank's partial of attn_output / ffn_down, all-reduced into x
+  float* zeros = nullptr;  // tp > 1: the 'residual' of ranks != 0
+  bool allocated = false;  // buffers exist (set by tl_model_finalize, also when the graph is skipped)
+  ncclComm_t comm = nullptr;
   std::vector<LayerW> layers;
   tl_qweight* tok = nullptr;
   tl_qweight* out = nullptr;
@@ -88,13 +97,29 @@ extern "C" int tl_model_create(const tl_model_config* cfg, tl_model** out) {
              cfg->num_attention_heads, cfg->num_key_value_heads);
   TL_REQUIRE(cfg->hidden_size % 32 == 0 && cfg->intermediate_size % 32 == 0, "tl_model_create: sizes must be multiples of 32");
   const int tp = cfg->tp_size <= 0 ? 1 : cfg->tp_size;
-  TL_REQUIRE(tp == 1, "tl_model_create: tp_size %d: tensor parallel shards are not wired up in this build", tp);
+  const int hd = cfg->hidden_size / cfg->num_attention_heads;
+  TL_REQUIRE(cfg->tp_rank >= 0 && cfg->tp_rank < tp, "tl_model_create: tp_rank %d outside [0,%d)", cfg->tp_rank, tp);
+  // Megatron-style shards: q/k/v/gate/up/output by output rows (heads, intermediate columns, vocab rows),
+  // attn_output/ffn_down by input columns, which must fall on 256-element super-block boundaries
+  TL_REQUIRE(cfg->num_attention_heads % tp == 0 && cfg->num_key_value_heads % tp == 0 &&
+                 cfg->intermediate_size % tp == 0 && cfg->vocab_size % tp == 0,
+             "tl_model_create: tp_size %d does not divide heads %d / kv heads %d / intermediate %d / vocab %d", tp,
+             cfg->num_attention_heads, cfg->num_key_value_heads, cfg->intermediate_size, cfg->vocab_size);
+  TL_REQUIRE(tp == 1 || ((cfg->num_attention_heads / tp * hd) % 256 == 0 && (cfg->intermediate_size / tp) % 256 == 0),
+             "tl_model_create: tp_size %d: column shards of attn_output (%d) / ffn_down (%d) are not multiples of 256", tp,
+             cfg->num_attention_heads / tp * hd, cfg->intermediate_size / tp);
   tl_model* m = new tl_model();
   m->cfg = *cfg;
   m->cfg.tp_size = tp;
-  m->cfg.tp_rank = 0;
-  m->head_dim = cfg->hidden_size / cfg->num_attention_heads;
-  m->kv_dim = m->head_dim * cfg->num_key_value_heads;
+  m->tp = tp;
+  m->rank = cfg->tp_rank;
+  m->head_dim = hd;
+  m->nh_l = cfg->num_attention_heads / tp;
+  m->nkv_l = cfg->num_key_value_heads / tp;
+  m->I_l = cfg->intermediate_size / tp;
+  m->V_l = cfg->vocab_size / tp;
+  m->qd_l = m->nh_l * hd;
+  m->kv_dim = hd * m->nkv_l;
   m->layers.resize(cfg->num_hidden_layers);
   hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -118,7 +143,8 @@ extern "C" int tl_model_free(tl_model* m) {
   }
   tl_qweight_free(m->tok);
   tl_qweight_free(m->out);
-  float* bufs[] = {m->out_norm, m->kv_base, m->x, m->q, m->k, m->v, m->att, m->h, m->logits, m->rope};
+  if (m->comm) ncclCommDestroy(m->comm);
+  float* bufs[] = {m->out_norm, m->kv_base, m->x, m->xp, m->zeros, m->q, m->k, m->v, m->att, m->h, m->logits, m->rope};
   for (float* b : bufs) hipFree(b);
   hipFree(m->state);
   hipFree(m->cand_v);
@@ -134,8 +160,8 @@ extern "C" int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, c
   TL_REQUIRE(m && host_data, "tl_model_set_tensor: null argument");
   TL_REQUIRE(!m->finalized, "tl_model_set_tensor: model already finalized");
   const tl_model_config& c = m->cfg;
-  const int H = c.hidden_size, I = c.intermediate_size, V = c.vocab_size;
-  const int qd = H, kvd = m->kv_dim;
+  const int H = c.hidden_size, I = m->I_l, V = c.vocab_size;  // I: this rank's share
+  const int qd = m->qd_l, kvd = m->kv_dim;
   if (kind == TL_T_ATTN_NORM || kind == TL_T_FFN_NORM || kind == TL_T_OUTPUT_NORM) {
     // norms must be F32 tensors (weight_management.cpp:838,926,957)
     TL_REQUIRE(type == TL_F32, "tl_model_set_tensor: norm weights must be F32 (got type %d)", type);
@@ -151,20 +177,21 @@ extern "C" int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, c
     case TL_T_ATTN_Q: er = qd; ec = H; break;
     case TL_T_ATTN_K: er = kvd; ec = H; break;
     case TL_T_ATTN_V: er = kvd; ec = H; break;
-    case TL_T_ATTN_OUTPUT: er = H; ec = qd; break;
+    case TL_T_ATTN_OUTPUT: er = H; ec = qd; break;  // column shard
     case TL_T_FFN_GATE: er = I; ec = H; break;
     case TL_T_FFN_UP: er = I; ec = H; break;
     case TL_T_FFN_DOWN: er = H; ec = I; break;
     case TL_T_TOKEN_EMBD: er = V; ec = H; slot = &m->tok; break;
-    case TL_T_OUTPUT: er = V; ec = H; slot = &m->out; break;
+    case TL_T_OUTPUT: er = m->V_l; ec = H; slot = &m->out; break;  // vocab-row shard
     default: TL_REQUIRE(false, "tl_model_set_tensor: unknown tensor kind %d", kind);
   }
   if (!slot) {
     TL_REQUIRE(layer >= 0 && layer < c.num_hidden_layers, "tl_model_set_tensor: layer %d out of range", layer);
     slot = &m->layers[layer].q[kind];
   }
-  TL_REQUIRE(rows == er && cols == ec, "tl_model_set_tensor: kind %d has shape %d x %d, config expects %d x %d", kind,
-             rows, cols, er, ec);
+  TL_REQUIRE(rows == er && cols == ec,
+             "tl_model_set_tensor: kind %d has shape %d x %d, config expects %d x %d (tp rank %d of %d: pass this rank's shard)",
+             kind, rows, cols, er, ec, m->rank, m->tp);
   if (*slot) {
     tl_qweight_free(*slot);
     *slot = nullptr;
@@ -320,18 +347,20 @@ static GemvArgs args_qkv(tl_model* m, int l) {
   a.role = GEMV_QKV;
   return a;
 }
+// tp > 1: the row-split projections (attn_output, ffn_down) write this rank's PARTIAL sum into xp; rank 0 folds the
+// residual into its partial, so that the all-reduce (sum) of the partials is the new residual stream on every rank.
 static GemvArgs args_attn_out(tl_model* m, int l) {
   GemvArgs o = {};
-  o.seg[0] = {qw_view(m->layers[l].q[TL_T_ATTN_OUTPUT]), m->x};
+  o.seg[0] = {qw_view(m->layers[l].q[TL_T_ATTN_OUTPUT]), m->tp > 1 ? m->xp : m->x};
   o.nseg = 1;
-  o.cols = m->cfg.hidden_size;
+  o.cols = m->qd_l;
   o.x = m->att;
   if (m->attn_split) {  // the attention output is still in split partials: combined while staging x
     o.attn_ws = m->attn_ws;
     o.attn_pos = m->state + 1;
     o.attn_hd = m->head_dim;
   }
-  o.resid = m->x;
+  o.resid = m->rank == 0 ? m->x : m->zeros;
   o.role = GEMV_ATTN_OUT;
   return o;
 }
@@ -351,17 +380,17 @@ static GemvArgs args_gate_up(tl_model* m, int l) {
 }
 static GemvArgs args_down(tl_model* m, int l) {
   GemvArgs d = {};
-  d.seg[0] = {qw_view(m->layers[l].q[TL_T_FFN_DOWN]), m->x};
+  d.seg[0] = {qw_view(m->layers[l].q[TL_T_FFN_DOWN]), m->tp > 1 ? m->xp : m->x};
   d.nseg = 1;
-  d.cols = m->cfg.intermediate_size;
+  d.cols = m->I_l;
   d.x = m->h;
-  d.resid = m->x;
+  d.resid = m->rank == 0 ? m->x : m->zeros;
   d.role = GEMV_DOWN;
   return d;
 }
 static GemvArgs args_lm_head(tl_model* m) {
   GemvArgs f = {};
-  f.seg[0] = {qw_view(m->out), m->logits};
+  f.seg[0] = {qw_view(m->out), m->logits + (size_t)m->rank * m->V_l};  // this rank's vocab rows
   f.nseg = 1;
   f.cols = m->cfg.hidden_size;
   f.x = m->x;
@@ -371,57 +400,176 @@ static GemvArgs args_lm_head(tl_model* m) {
   return f;
 }
 
-static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
+#define TL_NCCL(expr)                                                                            \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess) {                                                                     \
+      tl_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr, ncclGetErrorString(r_)); \
+      return 4;                                                                                  \
+    }                                                                                            \
+  } while (0)
+
+// x = sum over ranks of xp (RCCL over xGMI; one f32[hidden_size] all-reduce per row-split projection)
+static int tp_all_reduce(tl_model* m, hipStream_t s) {
+  if (m->tp == 1) return 0;
+  TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
+  TL_NCCL(ncclAllReduce(m->xp, m->x, (size_t)m->cfg.hidden_size, ncclFloat, ncclSum, m->comm, s));
+  return 0;
+}
+
+// ---- the step in pieces, so that a group of shards living in ONE process can be driven in lockstep (tests) ------------
+static int enqueue_embed(tl_model* m, hipStream_t s) {
+  return tl_launch_dequant_rows(m->tok, m->state, 0, 1, m->x, s);
+}
+// norm + QKV GEMV, RoPE + KV write + attention, attn_output GEMV (-> x, or the partial xp when tp > 1)
+static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
   const tl_model_config& c = m->cfg;
-  hipStream_t s = m->stream;
-  const int* tok_dev = m->state;
   const int* pos_dev = m->state + 1;
   const float scale = 1.0f / sqrtf((float)m->head_dim);
+  TL_TRY(tl_launch_gemv(args_qkv(m, l), s));
+  PROF_MARK(1);
+  if (m->attn_split) {  // RoPE + KV write + split attention in one launch
+    AttnArgs t = {};
+    t.q = m->q;
+    t.k = m->k;
+    t.v = m->v;
+    t.kc = m->kc(l);
+    t.vc = m->vc(l);
+    t.table = m->rope;
+    t.out = m->att;
+    t.ws = m->attn_ws;
+    t.nh = m->nh_l;
+    t.nkv = m->nkv_l;
+    t.hd = m->head_dim;
+    t.pos_dev = pos_dev;
+    t.max_seq = c.max_position_embeddings;
+    t.scale = scale;
+    PROF_MARK(2);
+    TL_TRY(tl_launch_attn_split(t, true, s));
+  } else {
+    TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, m->nh_l, m->nkv_l, m->head_dim, pos_dev,
+                             c.max_position_embeddings, s));
+    PROF_MARK(2);
+    TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, m->nh_l, m->nkv_l, m->head_dim, 0, pos_dev,
+                                 c.max_position_embeddings, scale, s));
+  }
+  PROF_MARK(3);
+  return tl_launch_gemv(args_attn_out(m, l), s);
+}
+// norm + gate/up GEMV + SwiGLU, ffn_down GEMV (-> x, or the partial xp when tp > 1)
+static int enqueue_mlp_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
+  TL_TRY(tl_launch_gemv(args_gate_up(m, l), s));
+  PROF_MARK(5);
+  return tl_launch_gemv(args_down(m, l), s);
+}
+static int enqueue_head(tl_model* m, hipStream_t s) { return tl_launch_gemv(args_lm_head(m), s); }
+static int enqueue_sample(tl_model* m, hipStream_t s) {
+  const int V = m->cfg.vocab_size;
+  argmax_slices_kernel<<<ARGMAX_SLICES, ARGMAX_THREADS, 0, s>>>(m->logits, V, m->cand_v, m->cand_i);
+  sample_advance_kernel<<<1, 256, 0, s>>>(m->logits, V, m->cand_v, m->cand_i, m->state, m->hist_cap);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
+  hipStream_t s = m->stream;
   PROF_MARK(-1);
-  TL_TRY(tl_launch_dequant_rows(m->tok, tok_dev, 0, 1, m->x, s));
+  TL_TRY(enqueue_embed(m, s));
   PROF_MARK(0);
-  for (int l = 0; l < c.num_hidden_layers; ++l) {
-    TL_TRY(tl_launch_gemv(args_qkv(m, l), s));
-    PROF_MARK(1);
-    if (m->attn_split) {  // RoPE + KV write + split attention in one launch
-      AttnArgs t = {};
-      t.q = m->q;
-      t.k = m->k;
-      t.v = m->v;
-      t.kc = m->kc(l);
-      t.vc = m->vc(l);
-      t.table = m->rope;
-      t.out = m->att;
-      t.ws = m->attn_ws;
-      t.nh = c.num_attention_heads;
-      t.nkv = c.num_key_value_heads;
-      t.hd = m->head_dim;
-      t.pos_dev = pos_dev;
-      t.max_seq = c.max_position_embeddings;
-      t.scale = scale;
-      PROF_MARK(2);
-      TL_TRY(tl_launch_attn_split(t, true, s));
-    } else {
-      TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, c.num_attention_heads,
-                               c.num_key_value_heads, m->head_dim, pos_dev, c.max_position_embeddings, s));
-      PROF_MARK(2);
-      TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, c.num_attention_heads, c.num_key_value_heads,
-                                   m->head_dim, 0, pos_dev, c.max_position_embeddings, scale, s));
-    }
-    PROF_MARK(3);
-    TL_TRY(tl_launch_gemv(args_attn_out(m, l), s));
+  for (int l = 0; l < m->cfg.num_hidden_layers; ++l) {
+    TL_TRY(enqueue_attn_half(m, l, s, prof));
+    TL_TRY(tp_all_reduce(m, s));
     PROF_MARK(4);
-    TL_TRY(tl_launch_gemv(args_gate_up(m, l), s));
-    PROF_MARK(5);
-    TL_TRY(tl_launch_gemv(args_down(m, l), s));
+    TL_TRY(enqueue_mlp_half(m, l, s, prof));
+    TL_TRY(tp_all_reduce(m, s));
     PROF_MARK(6);
   }
-  TL_TRY(tl_launch_gemv(args_lm_head(m), s));
+  TL_TRY(enqueue_head(m, s));
+  if (m->tp > 1) {  // every rank gets the full logits (in place: its own rows already sit at rank * V_l) and samples
+    TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
+    TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
+  }
   PROF_MARK(7);
-  argmax_slices_kernel<<<ARGMAX_SLICES, ARGMAX_THREADS, 0, s>>>(m->logits, c.vocab_size, m->cand_v, m->cand_i);
-  sample_advance_kernel<<<1, 256, 0, s>>>(m->logits, c.vocab_size, m->cand_v, m->cand_i, m->state, m->hist_cap);
-  TL_HIP(hipGetLastError());
+  TL_TRY(enqueue_sample(m, s));
   PROF_MARK(8);
+  return 0;
+}
+
+// ---- a whole tensor-parallel group inside ONE process on ONE device (parity tests of the sharded path on a single
+//      GPU; the collectives are plain kernels here, RCCL is only needed across processes) ---------------------------
+__global__ void group_sum_kernel(const float* const* __restrict__ parts, float* const* __restrict__ outs, int n, int len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float acc = 0.f;
+  for (int r = 0; r < n; ++r) acc += parts[r][i];  // rank order, like a ring reduce started at rank 0
+  for (int r = 0; r < n; ++r) outs[r][i] = acc;
+}
+
+extern "C" int tl_tp_local_group_decode(tl_model* const* ms, int n, int token_id, int pos, float* logits_host,
+                                        int* next_token_host) {
+  TL_REQUIRE(ms && n >= 1 && n <= 16, "tl_tp_local_group_decode: bad group");
+  tl_model* m0 = ms[0];
+  for (int r = 0; r < n; ++r) {
+    TL_REQUIRE(ms[r] && ms[r]->allocated && ms[r]->tp == n && ms[r]->rank == r,
+               "tl_tp_local_group_decode: member %d is not rank %d of a finalized %d-way group", r, r, n);
+    TL_REQUIRE(ms[r]->cfg.hidden_size == m0->cfg.hidden_size && ms[r]->cfg.vocab_size == m0->cfg.vocab_size,
+               "tl_tp_local_group_decode: members disagree on the model shape");
+  }
+  TL_REQUIRE(pos >= 0 && pos < m0->cfg.max_position_embeddings, "tl_tp_local_group_decode: pos %d out of range", pos);
+  hipStream_t s = m0->stream;
+  const int H = m0->cfg.hidden_size, V = m0->cfg.vocab_size;
+  std::vector<const float*> parts(n);
+  std::vector<float*> outs(n);
+  for (int r = 0; r < n; ++r) {
+    parts[r] = ms[r]->xp;
+    outs[r] = ms[r]->x;
+  }
+  const float** parts_dev = nullptr;
+  float** outs_dev = nullptr;
+  TL_HIP(hipMalloc(&parts_dev, sizeof(float*) * n));
+  TL_HIP(hipMalloc(&outs_dev, sizeof(float*) * n));
+  TL_HIP(hipMemcpy(parts_dev, parts.data(), sizeof(float*) * n, hipMemcpyHostToDevice));
+  TL_HIP(hipMemcpy(outs_dev, outs.data(), sizeof(float*) * n, hipMemcpyHostToDevice));
+  int rc = 0;
+  auto all = [&](auto&& f) {
+    for (int r = 0; r < n && rc == 0; ++r) rc = f(ms[r]);
+  };
+  auto reduce = [&]() {
+    if (rc == 0 && n > 1) group_sum_kernel<<<(H + 255) / 256, 256, 0, s>>>(parts_dev, outs_dev, n, H);
+  };
+  for (int r = 0; r < n && rc == 0; ++r) {
+    const int st[4] = {token_id, pos, 0, 0x3f800000};
+    if (hipMemcpyAsync(ms[r]->state, st, sizeof(st), hipMemcpyHostToDevice, s) != hipSuccess) rc = 1;
+  }
+  if (rc == 0 && hipStreamSynchronize(s) != hipSuccess) rc = 1;  // `st` is a stack buffer
+  all([&](tl_model* m) { return enqueue_embed(m, s); });
+  for (int l = 0; l < m0->cfg.num_hidden_layers && rc == 0; ++l) {
+    all([&](tl_model* m) { return enqueue_attn_half(m, l, s, nullptr); });
+    reduce();
+    all([&](tl_model* m) { return enqueue_mlp_half(m, l, s, nullptr); });
+    reduce();
+  }
+  all([&](tl_model* m) { return enqueue_head(m, s); });
+  if (rc == 0 && n > 1) {  // all-gather: rank r's vocab rows into everybody's logits
+    for (int r = 0; r < n && rc == 0; ++r)
+      for (int q = 0; q < n && rc == 0; ++q)
+        if (q != r && hipMemcpyAsync(ms[q]->logits + (size_t)r * ms[r]->V_l, ms[r]->logits + (size_t)r * ms[r]->V_l,
+                                     sizeof(float) * (size_t)ms[r]->V_l, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          rc = 1;
+  }
+  all([&](tl_model* m) { return enqueue_sample(m, s); });
+  if (rc == 0 && logits_host &&
+      hipMemcpyAsync(logits_host, m0->logits, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s) != hipSuccess)
+    rc = 1;
+  if (rc == 0 && next_token_host &&
+      hipMemcpyAsync(next_token_host, m0->state, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess)
+    rc = 1;
+  const hipError_t e = hipStreamSynchronize(s);
+  hipFree(parts_dev);
+  hipFree(outs_dev);
+  if (rc > 1) return rc;
+  TL_REQUIRE(rc == 0, "tl_tp_local_group_decode: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  TL_HIP(e);
   return 0;
 }
 
@@ -500,34 +648,56 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->kv_base, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers));
   TL_HIP(hipMemsetAsync(m->kv_base, 0, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers, m->stream));
   TL_HIP(hipMalloc(&m->x, sizeof(float) * H));
-  TL_HIP(hipMalloc(&m->q, sizeof(float) * H));
+  TL_HIP(hipMalloc(&m->q, sizeof(float) * (size_t)m->qd_l));
+  if (m->tp > 1) {
+    TL_HIP(hipMalloc(&m->xp, sizeof(float) * H));
+    TL_HIP(hipMalloc(&m->zeros, sizeof(float) * H));
+    TL_HIP(hipMemsetAsync(m->zeros, 0, sizeof(float) * H, m->stream));
+  }
   TL_HIP(hipMalloc(&m->k, sizeof(float) * m->kv_dim));
   TL_HIP(hipMalloc(&m->v, sizeof(float) * m->kv_dim));
-  TL_HIP(hipMalloc(&m->att, sizeof(float) * H));
-  TL_HIP(hipMalloc(&m->h, sizeof(float) * I));
+  TL_HIP(hipMalloc(&m->att, sizeof(float) * (size_t)m->qd_l));
+  TL_HIP(hipMalloc(&m->h, sizeof(float) * (size_t)m->I_l));
+  (void)I;
   TL_HIP(hipMalloc(&m->logits, sizeof(float) * V));
   TL_HIP(hipMalloc(&m->rope, sizeof(float) * P * m->head_dim));
   TL_TRY(tl_rope_table_upload(m->rope, (int)P, m->head_dim, c.rope_theta, m->stream));
   TL_HIP(hipMalloc(&m->cand_v, sizeof(float) * ARGMAX_SLICES));
   TL_HIP(hipMalloc(&m->cand_i, sizeof(int) * ARGMAX_SLICES));
-  m->attn_split = tl_attn_split_supported(c.num_attention_heads, c.num_key_value_heads, m->head_dim);
-  if (m->attn_split)
-    TL_HIP(hipMalloc(&m->attn_ws, sizeof(float) * tl_attn_ws_floats(c.num_attention_heads, m->head_dim)));
+  m->attn_split = tl_attn_split_supported(m->nh_l, m->nkv_l, m->head_dim);
+  if (m->attn_split) TL_HIP(hipMalloc(&m->attn_ws, sizeof(float) * tl_attn_ws_floats(m->nh_l, m->head_dim)));
   m->hist_cap = (int)P + 64;
   TL_HIP(hipMalloc(&m->state, sizeof(int) * (kStateHeaderInts + m->hist_cap)));
   TL_HIP(hipMemsetAsync(m->state, 0, sizeof(int) * (kStateHeaderInts + m->hist_cap), m->stream));
+  m->allocated = true;
+  if (m->tp > 1 && !m->comm) {
+    // a shard without a communicator: only usable through tl_tp_local_group_decode (all shards in one process)
+    TL_HIP(hipStreamSynchronize(m->stream));
+    m->no_graph = true;
+    m->finalized = true;
+    return 0;
+  }
   // one eager step (position 0) outside capture: sets kernel attributes and validates every launch
   TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));
   TL_TRY(enqueue_step(m));
   TL_HIP(hipStreamSynchronize(m->stream));
   if (const char* e = getenv("TL_NO_GRAPH")) m->no_graph = atoi(e) != 0;
-  // capture the step once
-  TL_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-  int rc = enqueue_step(m);
-  hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
-  if (rc != 0) return rc;
-  TL_HIP(e);
-  TL_HIP(hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0));
+  if (!m->no_graph) {  // capture the step once
+    TL_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    int rc = enqueue_step(m);
+    hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
+    if (rc == 0 && e == hipSuccess) e = hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0);
+    if (rc != 0 || e != hipSuccess) {
+      if (m->tp == 1) {
+        if (rc != 0) return rc;
+        TL_HIP(e);
+      }
+      // tensor parallel: a collective library that cannot be captured -> replay the step eagerly instead
+      (void)hipGetLastError();
+      m->graph_exec = nullptr;
+      m->no_graph = true;
+    }
+  }
   // the warm-up step wrote position 0 of the cache: clear it again
   TL_HIP(hipMemsetAsync(m->kv_base, 0, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
@@ -544,6 +714,7 @@ extern "C" int tl_model_reset_kv(tl_model* m) {
 
 extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits_host, int* next_token_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_decode: model not finalized");
+  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_decode: a shard without a communicator runs only in tl_tp_local_group_decode");
   TL_REQUIRE(pos >= 0 && pos < m->cfg.max_position_embeddings, "tl_model_decode: pos %d outside [0,%d)", pos,
              m->cfg.max_position_embeddings);
   TL_TRY(set_state(m, token_id, pos, 1.0f, nullptr, 0));
@@ -559,6 +730,7 @@ extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits
 extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
                                         const int* history_host, int n_history, int* out_ids_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_generate_greedy: model not finalized");
+  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_generate_greedy: a shard without a communicator runs only in tl_tp_local_group_decode");
   TL_REQUIRE(n_steps >= 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
              "tl_model_generate_greedy: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + n_steps,
              m->cfg.max_position_embeddings);
@@ -586,6 +758,7 @@ __global__ void set_token_kernel(int* state, const int* tokens, int i) { state[0
 extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos,
                                 float* last_logits_host, float* all_logits_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_prefill: model not finalized");
+  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_prefill: a shard without a communicator runs only in tl_tp_local_group_decode");
   TL_REQUIRE(tokens_host && num_tokens > 0, "tl_model_prefill: empty prompt");
   TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m->cfg.max_position_embeddings,
              "tl_model_prefill: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + num_tokens,
@@ -615,6 +788,7 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
 extern "C" int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_steps, float* kind_ms_out,
                                        int* kind_launches_out) {
   TL_REQUIRE(m && m->finalized && kind_ms_out && kind_launches_out, "tl_model_profile_decode: bad argument");
+  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_profile_decode: a shard without a communicator cannot step alone");
   TL_REQUIRE(n_steps > 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
              "tl_model_profile_decode: positions out of range");
   for (int k = 0; k < 9; ++k) {
@@ -663,15 +837,21 @@ extern "C" int tl_model_bytes_per_token(const tl_model* m, int pos, double* weig
 }
 
 extern "C" int tl_tp_unique_id(void* id_out_128) {
-  (void)id_out_128;
-  tl_set_error("tl_tp_unique_id: tensor parallelism is not wired up in this build");
-  return 3;
+  TL_REQUIRE(id_out_128, "tl_tp_unique_id: null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  TL_NCCL(ncclGetUniqueId(&id));
+  memcpy(id_out_128, &id, sizeof(id));
+  return 0;
 }
 extern "C" int tl_model_tp_init(tl_model* m, const void* unique_id_128) {
-  (void)m;
-  (void)unique_id_128;
-  tl_set_error("tl_model_tp_init: tensor parallelism is not wired up in this build");
-  return 3;
+  TL_REQUIRE(m && unique_id_128, "tl_model_tp_init: null argument");
+  TL_REQUIRE(!m->finalized, "tl_model_tp_init: call before tl_model_finalize (the decode graph captures the collectives)");
+  if (m->tp == 1) return 0;
+  ncclUniqueId id;
+  memcpy(&id, unique_id_128, sizeof(id));
+  TL_NCCL(ncclCommInitRank(&m->comm, m->tp, id, m->rank));
+  return 0;
 }
 
 // ---- operator-level batched mat-mul (prefill): Y[T][rows] = X[T][cols] W^T ----------------------------------

@@ -8,7 +8,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import capi
+from . import capi, tp
 from .capi import check, lib
 
 _initialized = False
@@ -103,6 +103,24 @@ class QWeight:
             pass
 
 
+def tp_unique_id():
+    """128 bytes identifying a new RCCL communicator (rank 0 creates it, the host broadcasts it)."""
+    buf = (C.c_ubyte * 128)()
+    check(lib().tl_tp_unique_id(buf), "tl_tp_unique_id")
+    return bytes(buf)
+
+
+def tp_local_group_decode(models, token, pos, want_logits=True):
+    """One decode step of a tensor-parallel group whose shards all live in this process (test hook)."""
+    n = len(models)
+    arr = (C.c_void_p * n)(*[m.h for m in models])
+    logits = np.empty(models[0].cfg["vocab"], np.float32) if want_logits else None
+    nxt = C.c_int(-1)
+    check(lib().tl_tp_local_group_decode(arr, n, int(token), int(pos), logits.ctypes.data if want_logits else None,
+                                         C.byref(nxt)), "tl_tp_local_group_decode")
+    return logits, nxt.value
+
+
 KINDS = {"attn_q": capi.T_ATTN_Q, "attn_k": capi.T_ATTN_K, "attn_v": capi.T_ATTN_V,
          "attn_output": capi.T_ATTN_OUTPUT, "ffn_gate": capi.T_FFN_GATE, "ffn_up": capi.T_FFN_UP,
          "ffn_down": capi.T_FFN_DOWN, "attn_norm": capi.T_ATTN_NORM, "ffn_norm": capi.T_FFN_NORM}
@@ -127,7 +145,11 @@ class Model:
     """The device-resident model (tl_model): cfg is a dict with the synth.SHAPES keys."""
 
     def __init__(self, cfg, tp_rank=0, tp_size=1):
+        """tp_size > 1: this handle is shard `tp_rank` of a tensor-parallel group (tp.py). set_tensor() still takes the
+        FULL tensors and slices them; call tp_init(unique_id) before finalize() when the ranks are separate processes."""
         _ensure_init()
+        tp.check(cfg, tp_size)
+        self.tp_rank, self.tp_size = int(tp_rank), int(tp_size)
         self.cfg = dict(cfg)
         c = capi.ModelConfig(cfg["hidden"], cfg["inter"], cfg["n_heads"], cfg["n_kv_heads"], cfg["n_layers"],
                              cfg["vocab"], cfg["max_pos"], cfg["eps"], cfg["rope_theta"], tp_rank, tp_size)
@@ -137,6 +159,7 @@ class Model:
 
     def set_tensor(self, name, typ, arr, rows, cols):
         kind, layer = tensor_kind(name)
+        arr, rows, cols = tp.shard_tensor(name, typ, arr, rows, cols, self.tp_rank, self.tp_size)
         arr = np.ascontiguousarray(arr)
         check(lib().tl_model_set_tensor(self.h, kind, layer, typ, arr.ctypes.data, rows, cols),
               f"tl_model_set_tensor({name})")
@@ -146,6 +169,11 @@ class Model:
             self.set_tensor(name, typ, arr, rows, cols)
         self.finalize()
         return self
+
+    def tp_init(self, unique_id):
+        """Join the RCCL communicator of the group (unique_id: 128 bytes from tp_unique_id() on rank 0)."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        check(lib().tl_model_tp_init(self.h, buf), "tl_model_tp_init")
 
     def finalize(self):
         check(lib().tl_model_finalize(self.h), "tl_model_finalize")

@@ -73,6 +73,8 @@ SHAPES = {
                  eps=1e-5, rope_theta=10000.0),
     "tiny-gqa": dict(hidden=512, inter=1024, n_heads=8, n_kv_heads=2, n_layers=2, vocab=512, max_pos=256,
                      eps=1e-5, rope_theta=10000.0),
+    "tiny-tp": dict(hidden=1024, inter=2048, n_heads=16, n_kv_heads=4, n_layers=2, vocab=512, max_pos=128,
+                    eps=1e-5, rope_theta=10000.0),
     "tinyllama-1.1b": dict(hidden=2048, inter=5632, n_heads=32, n_kv_heads=4, n_layers=22, vocab=32000,
                            max_pos=2048, eps=1e-5, rope_theta=10000.0),
     "llama-3.2-3b": dict(hidden=3072, inter=8192, n_heads=24, n_kv_heads=8, n_layers=28, vocab=128256,

@@ -8,6 +8,10 @@ the north star's target is quoted on and that fits one GPU: Llama-3-8B-shaped sy
 
     python bench.py --gpus 1 --steps 128 --warmup 16 [--workload llama-3-8b|tinyllama-1.1b|llama-3.2-3b|tiny]
 
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) the SAME sequence is decoded by a tensor-parallel
+group: every rank holds 1/N of every projection (tp.py), two f32[hidden] RCCL all-reduces per layer and one logits
+all-gather per token run inside the captured step ("scaling": "strong": total work is fixed, per-GPU bytes = B_tok / N).
+
 Prints ONE JSON line (rank 0). Timing: barrier + device sync on both sides, max over ranks. `roofline` is for the
 dominant kernel (the fused RMSNorm + gate/up GEMV + SwiGLU launch): algorithmic bytes per launch / its average
 launch duration, measured with HIP events on the engine's stream over back-to-back launches that cycle through the
@@ -29,6 +33,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MIX = {"llama-3-8b": "q4_k_m", "tinyllama-1.1b": "q4_k_m", "llama-3.2-3b": "q6_k", "tiny": "q4_k_m",
        "tiny-gqa": "q4_k_m"}
+
+
+METRIC = "decode tokens/sec + achieved HBM GB/s (% of peak) at Q4_K_M, 1/2/4/8 GPU"
 
 
 def parse():
@@ -75,7 +82,29 @@ def main():
 
     # ---- build + upload the synthetic model tensor by tensor (host copy dropped right away) ---------------
     t_load = time.time()
-    model = engine.Model(cfg)
+    tp_err = None
+    try:
+        pkg_tp = __import__("tinyllama_cpp_amd.tp", fromlist=["check"])
+        pkg_tp.check(cfg, world)
+    except ValueError as e:  # this shape does not split `world` ways: say so and stop, on every rank
+        tp_err = str(e)
+    if tp_err:
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "tokens/s", "n_gpus": world,
+                              "error": f"workload {args.workload} cannot be tensor-parallel over {world} GPUs: {tp_err}"}))
+        if dist is not None:
+            dist.destroy_process_group()
+        return 1
+    model = engine.Model(cfg, tp_rank=rank, tp_size=world)
+    if world > 1:  # rank 0 makes the communicator id, torch.distributed carries it to the other ranks
+        import torch
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(engine.tp_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, src=0)
+        model.tp_init(uid.cpu().numpy().tobytes())
+    elif os.environ.get("TL_TP_SELFTEST"):  # one-rank communicator: the RCCL calls of the step on a single GPU
+        model.tp_init(engine.tp_unique_id())
     keep = {}  # host copies kept for the CPU-baseline sample: first layers + globals
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     for name, typ, rows, cols in plan:
@@ -132,11 +161,11 @@ def main():
     prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "r01_gate_up_traffic.json")
-    if args.workload == "llama-3-8b" and os.path.exists(tpath):  # PMC pass of this kernel on this workload (profiles/)
+    if args.workload == "llama-3-8b" and world == 1 and os.path.exists(tpath):  # PMC pass of this kernel on this workload (profiles/)
         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
 
     out = {
-        "metric": "decode tokens/sec + achieved HBM GB/s (% of peak) at Q4_K_M, 1/2/4/8 GPU",
+        "metric": METRIC,
         "value": round(tok_s, 2),
         "unit": "tokens/s",
         "n_gpus": world,
@@ -150,8 +179,12 @@ def main():
         "data": "synthetic random-init weights (GGUF block formats), fixed token-id prompt",
         "config": {"workload": f"{args.workload} {mix} greedy decode, batch 1, prompt {args.prompt_len}, "
                                f"positions {pos}..{pos + args.steps - 1}, f32 KV cache",
-                   "parallelism": "single GPU" if world == 1 else f"replicas x{world}",
-                   "weight_bytes_per_token": int(w_bytes), "kv_bytes_per_token_mid": int(kv_bytes)},
+                   "parallelism": "single GPU" if world == 1 else
+                                  f"tp{world}: row/column-split projections, 2 RCCL all-reduces of f32[{cfg['hidden']}] "
+                                  f"per layer + logits all-gather, "
+                                  f"{'inside the captured step graph' if model.graph_captured() else 'eager launches (capture refused)'}",
+                   "weight_bytes_per_token_per_gpu": int(w_bytes), "kv_bytes_per_token_mid_per_gpu": int(kv_bytes)},
+        # per GPU: every rank streams its own 1/N of the bytes in the same step time
         "hbm_gbps_whole_step": round((w_bytes + kv_bytes) / (dt / args.steps) / 1e9, 1),
         "hbm_frac_whole_step": round((w_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel<.., GEMV_GATE_UP> (RMSNorm + ffn_gate/ffn_up GEMV + SwiGLU)",
@@ -204,4 +237,4 @@ def cpu_baseline(cfg, keep, n_layers, w_bytes):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -186,6 +186,11 @@ int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, d
  * captured into the graph there. Replaces distributed_coordinator.cpp's MPI request routing. */
 int tl_tp_unique_id(void* id_out_128);
 int tl_model_tp_init(tl_model* m, const void* unique_id_128);
+/* Diagnostic (no counterpart in the reference): *captured_out = 1 when the decode step replays as one hipGraph, 0 when
+ * it is enqueued launch by launch (TL_NO_GRAPH=1, a shard without a communicator, or a collective that refused
+ * capture). With TL_TP_SELFTEST=1 in the environment tl_model_tp_init gives a tp_size-1 model a one-rank communicator,
+ * so the RCCL calls of the step and their capture can be exercised on one GPU. */
+int tl_model_graph_captured(const tl_model* m, int* captured_out);
 /* Test hook: ALL n shards of a tp_size = n model live in this process on this device (created with tp_rank = 0..n-1,
  * finalized without tl_model_tp_init); one decode step in lockstep, collectives as plain kernels. */
 int tl_tp_local_group_decode(tl_model* const* shards, int n, int token_id, int pos, float* logits_host,

@@ -54,3 +54,24 @@ def test_tp_rejects_bad_splits(pkg):
         E.Model(cfg, tp_rank=0, tp_size=4)  # 2 kv heads do not split 4 ways
     with pytest.raises(ValueError):
         E.Model(dict(pkg.synth.SHAPES["tiny"]), tp_rank=0, tp_size=2)  # 128-column shards of attn_output
+
+
+def test_rccl_calls_capture_on_one_rank(pkg, monkeypatch):
+    """The RCCL all-reduce / all-gather calls of the step, and their capture into the decode graph, on a one-rank
+    communicator (TL_TP_SELFTEST): the token stream must be the plain single-GPU one."""
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model("tiny-gqa", "q4_k_m", seed=5)
+    plain = E.Model(cfg).load(tensors)
+    want = plain.generate_greedy(3, 0, 24)
+    monkeypatch.setenv("TL_TP_SELFTEST", "1")
+    m = E.Model(cfg)
+    for name, (typ, arr, rows, cols) in tensors.items():
+        m.set_tensor(name, typ, arr, rows, cols)
+    m.tp_init(E.tp_unique_id())
+    m.finalize()
+    got = m.generate_greedy(3, 0, 24)
+    assert np.array_equal(got, want)
+    assert m.graph_captured(), "RCCL collectives were not captured into the decode graph (eager fallback)"
+    m.free()
+    plain.free()

@@ -411,9 +411,10 @@ static GemvArgs args_lm_head(tl_model* m) {
 
 // x = sum over ranks of xp (RCCL over xGMI; one f32[hidden_size] all-reduce per row-split projection)
 static int tp_all_reduce(tl_model* m, hipStream_t s) {
-  if (m->tp == 1) return 0;
+  if (m->tp == 1 && !m->comm) return 0;
   TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
-  TL_NCCL(ncclAllReduce(m->xp, m->x, (size_t)m->cfg.hidden_size, ncclFloat, ncclSum, m->comm, s));
+  // (tp == 1 with a communicator is the one-rank self-test of tl_model_tp_init: in place on x)
+  TL_NCCL(ncclAllReduce(m->tp > 1 ? m->xp : m->x, m->x, (size_t)m->cfg.hidden_size, ncclFloat, ncclSum, m->comm, s));
   return 0;
 }
 
@@ -485,7 +486,7 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
     PROF_MARK(6);
   }
   TL_TRY(enqueue_head(m, s));
-  if (m->tp > 1) {  // every rank gets the full logits (in place: its own rows already sit at rank * V_l) and samples
+  if (m->tp > 1 || m->comm) {  // every rank gets the full logits (in place: its own rows already sit at rank * V_l) and samples
     TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
     TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
   }
@@ -688,7 +689,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
     hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
     if (rc == 0 && e == hipSuccess) e = hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0);
     if (rc != 0 || e != hipSuccess) {
-      if (m->tp == 1) {
+      if (!m->comm) {
         if (rc != 0) return rc;
         TL_HIP(e);
       }
@@ -836,6 +837,12 @@ extern "C" int tl_model_bytes_per_token(const tl_model* m, int pos, double* weig
   return 0;
 }
 
+extern "C" int tl_model_graph_captured(const tl_model* m, int* captured_out) {
+  TL_REQUIRE(m && m->finalized && captured_out, "tl_model_graph_captured: bad argument");
+  *captured_out = m->graph_exec != nullptr && !m->no_graph;
+  return 0;
+}
+
 extern "C" int tl_tp_unique_id(void* id_out_128) {
   TL_REQUIRE(id_out_128, "tl_tp_unique_id: null argument");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
@@ -847,7 +854,10 @@ extern "C" int tl_tp_unique_id(void* id_out_128) {
 extern "C" int tl_model_tp_init(tl_model* m, const void* unique_id_128) {
   TL_REQUIRE(m && unique_id_128, "tl_model_tp_init: null argument");
   TL_REQUIRE(!m->finalized, "tl_model_tp_init: call before tl_model_finalize (the decode graph captures the collectives)");
-  if (m->tp == 1) return 0;
+  // tp_size 1 needs no communicator; TL_TP_SELFTEST=1 makes a one-rank communicator anyway, so that the RCCL calls and
+  // their graph capture can be exercised on a single GPU (tests/test_tp_gpu.py)
+  const char* st = getenv("TL_TP_SELFTEST");
+  if (m->tp == 1 && !(st && atoi(st) != 0)) return 0;
   ncclUniqueId id;
   memcpy(&id, unique_id_128, sizeof(id));
   TL_NCCL(ncclCommInitRank(&m->comm, m->tp, id, m->rank));

@@ -178,6 +178,12 @@ class Model:
     def finalize(self):
         check(lib().tl_model_finalize(self.h), "tl_model_finalize")
 
+    def graph_captured(self):
+        """True when the decode step replays as one hipGraph (False: eager launches, see tl_model_graph_captured)."""
+        out = C.c_int(0)
+        check(lib().tl_model_graph_captured(self.h, C.byref(out)), "tl_model_graph_captured")
+        return bool(out.value)
+
     def reset_kv(self):
         check(lib().tl_model_reset_kv(self.h), "tl_model_reset_kv")
 

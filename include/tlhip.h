@@ -71,6 +71,9 @@ int tl_matvec_q(const tl_qweight* w, const float* x_dev, float* y_dev, void* str
 /* Y[T][rows] = X[T][cols] W^T : replaces gemm_f32_f32_cuda / gemm_f32_to_bf16_f32_cuda via
  * smart_gemm_batch_cuda (model.cpp:2141-2249) for batched prefill. */
 int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream);
+/* bf16 MFMAs per FP32 product in tl_matmul_q (num_tokens >= 8) and, by default, in tl_model_prefill: both operands
+ * are split into bf16 planes and a product is assembled from 1 (plain bf16), 3 or 6 (default; FP32-grade) MFMAs. */
+int tl_gemm_set_terms(int terms);
 
 /* ---- glue operators (same argument meaning as the cuda_kernels.h wrappers they replace) ------- */
 /* rmsnorm_vector_cuda(_optimized) cuda_kernels.h:104,569: out = x*rsqrt(mean(x^2)+max(eps,1e-5))*w
@@ -152,6 +155,12 @@ int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_
  * last_logits_host[vocab] (may be NULL) = logits of the last token; all_logits_host[T][vocab] may be NULL */
 int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
                      float* all_logits_host);
+/* Batched-prefill numerics / routing of this model (no counterpart in the reference, whose GPU prefill is FP32
+ * cublasSgemm or BF16 cublasGemmEx by a T >= 4 rule, model.cpp:2152-2153): terms = bf16 MFMAs per FP32 product in the
+ * prefill GEMMs: 6 (default, FP32-grade, logits within the decode tolerance), 3 (~2^-17 per product), 1 (plain bf16),
+ * 0 = the process-wide value of tl_gemm_set_terms; prompts shorter than min_batch (default 8) and tensor-parallel
+ * shards replay the decode graph token by token. */
+int tl_model_set_prefill(tl_model* m, int terms, int min_batch);
 /* Measurement hook (no counterpart in the reference): `iters` back-to-back tl_matvec_q launches cycling through
  * `nw` equally-shaped matrices (use more than the 256 MiB Infinity Cache holds), timed with HIP events on `stream`. */
 int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int iters, int warmup,

@@ -292,7 +292,7 @@ def test_model_kv_cache_and_prefill_vs_oracle(E, pkg, oracle):
     X = np.stack([om.lookup_embedding(t) for t in toks])
     _, lb = om.forward_batch(X, 0)
     assert close(allb, lb, LOGIT_TOL).all(), np.abs(allb - lb).max()
-    assert np.array_equal(last, allb[-1])
+    assert close(last, allb[-1], LOGIT_TOL).all()  # last: fused norm + lm_head GEMV; allb: the MFMA GEMM
     for layer in (0, cfg["n_layers"] - 1):
         k, v = m.kv_cache(layer, 35)
         assert close(k, om.kcache(layer, 35), LOGIT_TOL).all(), np.abs(k - om.kcache(layer, 35)).max()

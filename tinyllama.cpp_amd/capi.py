@@ -69,6 +69,8 @@ SIGNATURES = {
     "tl_model_decode": [_vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
     "tl_model_generate_greedy": [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp],
     "tl_model_prefill": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
+    "tl_model_set_prefill": [_vp, C.c_int, C.c_int],
+    "tl_gemm_set_terms": [C.c_int],
     "tl_bench_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), _vp],
     "tl_bench_matvec_prefetch": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float)],
     "tl_debug_gemv_stamps": [_vp, _fp, _fp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp],

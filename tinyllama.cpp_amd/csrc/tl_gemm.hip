@@ -1,0 +1,345 @@
+// tl_gemm.hip — batched-prefill GEMM over the quantized plane layout on the matrix cores:
+//   Y[T][rows] (+ resid) = X[T][cols] . W[rows][cols]^T
+//
+// What it replaces: smart_gemm_batch_cuda -> cublasSgemm / cublasGemmEx(BF16) over FP32-expanded weights
+// (model.cpp:2141-2249, cuda_kernels.cu:2541-2701); the numerics target is the CPU path, matmul_f32_f32_batch_cpu
+// (utils.cpp:730-782: per token the Kahan-double dot of the exactly dequantized row).
+//
+// This is the one dense contraction of the path, so it runs on MFMA (v_mfma_f32_32x32x16_bf16, FP32 accumulate):
+//   - the weights never exist in HBM in expanded form: a workgroup loads the raw plane bytes of a 64-row x 32-column
+//     tile, dequantizes them in registers with the reference's exact FP32 expression (the same values as
+//     tl_dequantize_rows), and writes them to LDS as bf16;
+//   - precision: a bf16 has 8 significant bits, an FP32 weight or activation 24. Both operands are therefore split
+//     into up to three bf16 "planes" v = p0 + p1 + p2 (p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1); the
+//     subtractions are exact), and a product is assembled from 1, 3 or 6 MFMAs:
+//         terms = 1:  x0.w0                                  (plain bf16, error ~2^-9 per product)
+//         terms = 3:  + x0.w1 + x1.w0                        (~2^-17)
+//         terms = 6:  + x1.w1 + x0.w2 + x2.w0                (~2^-24: FP32-grade, the default)
+//     at 1/6 of the bf16 rate the 6-term form is still ~2.7x the chip's FP32 MFMA/VALU rate;
+//   - the activation planes are produced ONCE per GEMM input by the producer kernel (RMSNorm, SwiGLU or a plain
+//     split, below), not by every workgroup that consumes them;
+//   - tile: 128 tokens x 64 weight rows x 32 columns per step, 4 waves (each 64 tokens x 32 rows = two 32x32
+//     accumulators); LDS rows are padded to 80 B so that the 16 B/lane fragment reads are bank-conflict free; the
+//     next step's global loads are issued before the current step's MFMAs (register prefetch);
+//   - workgroup -> tile mapping is XCD-aware: the 8 XCDs (round-robin over blockIdx) each walk a contiguous range of
+//     weight-row tiles of ONE token panel, so a panel's activation planes (<= 3 MB) stay in that XCD's L2.
+#include <stdlib.h>
+
+#include "tl_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int GB_M = 64;    // weight rows per workgroup tile
+constexpr int GB_N = 128;   // tokens per workgroup tile
+constexpr int GB_K = 32;    // columns per step = one 32-weight chunk of the plane layout
+constexpr int GROW = 40;    // bf16 elements per LDS row (32 + 8 pad = 80 B)
+constexpr int GEMM_THREADS = 256;
+
+__device__ __forceinline__ float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
+__device__ __forceinline__ float h2f_scale(unsigned h) {  // |d| for finite negatives (quantization.cpp:85-87)
+  const float d = h2f(h);
+  return (d < 0.0f && d > -INFINITY) ? -d : d;
+}
+
+// ---- 8 consecutive weights (quarter `q` of 32-weight chunk `c` of `row`): raw bytes, then exact FP32 values --------
+struct Raw8 {
+  unsigned a, b;  // payload
+  u32x4 h;        // Q4_K super-block header / scale fields
+};
+
+template <int TYPE>
+__device__ __forceinline__ Raw8 load8(const QW& w, int row, int c, int q) {
+  Raw8 r = {};
+  const size_t R = (size_t)row, cols = (size_t)w.cols;
+  if (TYPE == TL_Q4_K) {
+    r.a = *reinterpret_cast<const unsigned*>(w.p0 + R * (cols >> 1) + (size_t)c * 16 + q * 4);
+    r.h = *reinterpret_cast<const u32x4*>(w.p1 + R * (cols >> 4) + (size_t)(c >> 3) * 16);
+  } else if (TYPE == TL_Q6_K) {
+    r.a = *reinterpret_cast<const unsigned*>(w.p0 + R * (cols >> 1) + (size_t)c * 16 + q * 4);
+    r.b = *reinterpret_cast<const unsigned*>(w.p1 + R * (cols >> 2) + (size_t)c * 8 + (q >> 1) * 4);
+    r.h[0] = *reinterpret_cast<const uint8_t*>(w.p2 + R * (cols >> 4) + (size_t)c * 2 + (q >> 1));
+    r.h[1] = *reinterpret_cast<const uint16_t*>(w.p3 + (R * (cols >> 8) + (size_t)(c >> 3)) * 2);
+  } else {  // Q8_0 / Q8_K
+    const u32x2 v = *reinterpret_cast<const u32x2*>(w.p0 + R * cols + (size_t)c * 32 + q * 8);
+    r.a = v[0];
+    r.b = v[1];
+    const size_t di = TYPE == TL_Q8_0 ? R * (cols >> 5) + (size_t)c : R * (cols >> 8) + (size_t)(c >> 3);
+    r.h[0] = *reinterpret_cast<const uint16_t*>(w.p1 + di * 2);
+  }
+  return r;
+}
+
+// the reference's expressions with every product / difference rounded separately (quantization.cpp:171-266,
+// 1009-1052): the values are bit-identical to tl_dequantize_rows
+template <int TYPE>
+__device__ __forceinline__ void deq8(const Raw8& r, int c, int q, float* y) {
+#pragma clang fp contract(off)
+  if (TYPE == TL_Q4_K) {
+    const int j = c & 7;
+    const float d = h2f(r.h[0] & 0xffffu), dmin = h2f(r.h[0] >> 16);
+    const unsigned sc = ((r.h[1] >> (4 * j)) & 15u) | (((r.h[3] >> (2 * j)) & 3u) << 4);
+    const unsigned mn = ((r.h[2] >> (4 * j)) & 15u) | (((r.h[3] >> (16 + 2 * j)) & 3u) << 4);
+    const float d1 = __fmul_rn(d, (float)sc), m1 = __fmul_rn(dmin, (float)mn);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned byte = (r.a >> (8 * t)) & 0xffu;
+      y[t] = __fsub_rn(__fmul_rn(d1, (float)(byte & 15u)), m1);
+      y[4 + t] = __fsub_rn(__fmul_rn(d1, (float)(byte >> 4)), m1);
+    }
+  } else if (TYPE == TL_Q6_K) {
+    const float ds = __fmul_rn(h2f(r.h[1]), (float)(int)(signed char)(r.h[0] & 0xffu));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int part = i >> 2, t = i & 3, g = 2 * (q & 1) + part;
+      const unsigned lo = (r.a >> (8 * t + 4 * part)) & 15u;
+      const unsigned hi = (r.b >> (8 * t + 2 * g)) & 3u;
+      y[i] = __fmul_rn(ds, (float)((int)(lo | (hi << 4)) - 32));
+    }
+  } else {
+    const float d = h2f_scale(r.h[0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned v = i < 4 ? r.a : r.b;
+      y[i] = __fmul_rn(d, (float)(int)(signed char)((v >> (8 * (i & 3))) & 0xffu));
+    }
+  }
+}
+
+// v = p0 + p1 + p2 with bf16 parts (round-to-nearest-even converts; the remainders are exact in FP32)
+template <int NP>
+__device__ __forceinline__ void split8(const float* v, bf16x8* planes) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float r = v[i];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const __bf16 b = (__bf16)r;
+      planes[p][i] = b;
+      r -= (float)b;
+    }
+  }
+}
+
+template <int TYPE, int NP, int NT>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
+                                                              float* __restrict__ y, const float* __restrict__ resid,
+                                                              int T, int mtiles, int ntiles) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ws[NP][GB_M * GROW];
+  __shared__ __attribute__((aligned(16))) __bf16 Xs[NP][GB_N * GROW];
+  const int M = w.rows, K = w.cols;
+  const int total = mtiles * ntiles;
+  int tile = blockIdx.x;
+  if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);  // contiguous range per XCD
+  const int nt = tile / mtiles, mt = tile - nt * mtiles;
+  const int m0 = mt * GB_M, n0 = nt * GB_N;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  // staging roles: weights (row, quarter of the chunk); activations: two 16-B pieces of the 128 x 64 B tile per plane
+  const int wrow = tid >> 2, wq = tid & 3;
+  const int grow = m0 + wrow < M ? m0 + wrow : M - 1;
+  const int xr0 = tid >> 2, xr1 = xr0 + 64, xs = tid & 3;
+  const __bf16* xg0 = xp + (size_t)(n0 + xr0) * K + xs * 8;
+  const __bf16* xg1 = xp + (size_t)(n0 + xr1) * K + xs * 8;
+  const int nk = K / GB_K;
+
+  Raw8 rw = load8<TYPE>(w, grow, 0, wq);
+  bf16x8 rx[NP][2];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride);
+    rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride);
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  for (int kk = 0; kk < nk; ++kk) {
+    {  // staged registers -> LDS (weights: dequantize + split on the way)
+      float wv[8];
+      deq8<TYPE>(rw, kk, wq, wv);
+      bf16x8 wp[NP];
+      split8<NP>(wv, wp);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        *reinterpret_cast<bf16x8*>(&Ws[p][wrow * GROW + wq * 8]) = wp[p];
+        *reinterpret_cast<bf16x8*>(&Xs[p][xr0 * GROW + xs * 8]) = rx[p][0];
+        *reinterpret_cast<bf16x8*>(&Xs[p][xr1 * GROW + xs * 8]) = rx[p][1];
+      }
+    }
+    __syncthreads();
+    {  // next step's loads (the last step re-reads itself: unconditional, so the waits stay counted)
+      const int kn = kk + 1 < nk ? kk + 1 : kk;
+      rw = load8<TYPE>(w, grow, kn, wq);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride + (size_t)kn * GB_K);
+        rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride + (size_t)kn * GB_K);
+      }
+    }
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16) {
+      bf16x8 a[NP][2], b[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        a[p][0] = *reinterpret_cast<const bf16x8*>(&Xs[p][(wn * 64 + fr) * GROW + k16 * 16 + fh * 8]);
+        a[p][1] = *reinterpret_cast<const bf16x8*>(&Xs[p][(wn * 64 + 32 + fr) * GROW + k16 * 16 + fh * 8]);
+        b[p] = *reinterpret_cast<const bf16x8*>(&Ws[p][(wm * 32 + fr) * GROW + k16 * 16 + fh * 8]);
+      }
+      // (x plane, w plane) pairs, smallest contributions first
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int t = 6 - NT; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t] < NP ? PA[t] : 0][i], b[PB[t] < NP ? PB[t] : 0],
+                                                           acc[i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // D[token][row]: column (weight row) on the lane, token rows in the 16 registers
+  const int m = m0 + wm * 32 + fr;
+  if (m < M) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (t < T) {
+          const size_t o = (size_t)t * M + m;
+          y[o] = resid ? resid[o] + acc[i][e] : acc[i][e];
+        }
+      }
+  }
+}
+
+// ---- producers of the activation planes ----------------------------------------------------------------------------
+// planes[p][t][k] bf16, t < Tpad (rows >= T are never written: a token row only ever meets its own output row)
+enum SplitMode { SPLIT_PLAIN = 0, SPLIT_RMSNORM = 1, SPLIT_SWIGLU = 2 };
+
+__device__ __forceinline__ void store_split(float v, __bf16* planes, size_t plane_stride, size_t idx, int np) {
+  for (int p = 0; p < np; ++p) {
+    const __bf16 b = (__bf16)v;
+    planes[p * plane_stride + idx] = b;
+    v -= (float)b;
+  }
+}
+
+// one workgroup per token. RMSNORM: rmsnorm_batch_cpu (utils.cpp:613-646): x * rsqrt(mean(x^2) + eps) * w.
+// SWIGLU: the batched form of cpu_batch_processor.cpp:252-256: (g / (1 + exp(-g))) * u.
+template <int MODE>
+__global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ aux,
+                                                    __bf16* __restrict__ planes, size_t plane_stride, int K, int np,
+                                                    float eps) {
+  __shared__ float red[4];
+  const int t = blockIdx.x;
+  const float* xt = x + (size_t)t * K;
+  float nf = 1.f;
+  if (MODE == SPLIT_RMSNORM) {
+    float ssq = 0.f;
+    for (int i = threadIdx.x; i < K; i += 256) ssq += xt[i] * xt[i];
+    for (int o = 32; o >= 1; o >>= 1) ssq += __shfl_xor(ssq, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
+    __syncthreads();
+    nf = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+  }
+  for (int i = threadIdx.x; i < K; i += 256) {
+    float v = xt[i];
+    if (MODE == SPLIT_RMSNORM) v = v * nf * aux[i];
+    if (MODE == SPLIT_SWIGLU) v = (v / (1.0f + expf(-v))) * aux[(size_t)t * K + i];
+    store_split(v, planes, plane_stride, (size_t)t * K + i, np);
+  }
+}
+
+int planes_of_terms(int terms) { return terms == 1 ? 1 : terms == 3 ? 2 : 3; }
+
+template <int TYPE>
+int launch_gemm_typed(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
+                      hipStream_t s) {
+  const int mtiles = (w.rows + GB_M - 1) / GB_M, ntiles = (T + GB_N - 1) / GB_N;
+  const dim3 grid(mtiles * ntiles), block(GEMM_THREADS);
+  if (terms == 1) gemm_q_kernel<TYPE, 1, 1><<<grid, block, 0, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  else if (terms == 3) gemm_q_kernel<TYPE, 2, 3><<<grid, block, 0, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  else gemm_q_kernel<TYPE, 3, 6><<<grid, block, 0, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+int g_gemm_terms = 6;
+
+}  // namespace
+
+int tl_gemm_default_terms() { return g_gemm_terms; }
+size_t tl_gemm_padded_tokens(int T) { return (size_t)((T + GB_N - 1) / GB_N) * GB_N; }
+
+int tl_launch_split(int mode, const float* x, const float* aux, void* planes, size_t plane_stride, int T, int K,
+                    int terms, float eps, hipStream_t s) {
+  if (T == 0) return 0;
+  const int np = planes_of_terms(terms);
+  __bf16* pl = static_cast<__bf16*>(planes);
+  if (mode == SPLIT_RMSNORM) split_kernel<SPLIT_RMSNORM><<<T, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  else if (mode == SPLIT_SWIGLU) split_kernel<SPLIT_SWIGLU><<<T, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  else split_kernel<SPLIT_PLAIN><<<T, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// planes: [planes_of_terms(terms)][plane_stride] bf16 with plane_stride >= tl_gemm_padded_tokens(T) * w.cols
+int tl_launch_gemm_q(const QW& w, const void* planes, size_t plane_stride, float* y, const float* resid, int T,
+                     int terms, hipStream_t s) {
+  TL_REQUIRE(terms == 1 || terms == 3 || terms == 6, "tl_launch_gemm_q: terms must be 1, 3 or 6 (got %d)", terms);
+  TL_REQUIRE(w.cols % GB_K == 0 && w.rows > 0, "tl_launch_gemm_q: bad weight shape %d x %d", w.rows, w.cols);
+  TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w.cols, "tl_launch_gemm_q: activation planes too small");
+  if (T == 0) return 0;
+  const __bf16* xp = static_cast<const __bf16*>(planes);
+  switch (w.type) {
+    case TL_Q4_K: return launch_gemm_typed<TL_Q4_K>(w, xp, plane_stride, y, resid, T, terms, s);
+    case TL_Q6_K: return launch_gemm_typed<TL_Q6_K>(w, xp, plane_stride, y, resid, T, terms, s);
+    case TL_Q8_0: return launch_gemm_typed<TL_Q8_0>(w, xp, plane_stride, y, resid, T, terms, s);
+    case TL_Q8_K: return launch_gemm_typed<TL_Q8_K>(w, xp, plane_stride, y, resid, T, terms, s);
+    default: TL_REQUIRE(false, "tl_launch_gemm_q: weight type %d has no MFMA path", w.type);
+  }
+  return 0;
+}
+
+extern "C" int tl_gemm_set_terms(int terms) {
+  TL_REQUIRE(terms == 1 || terms == 3 || terms == 6, "tl_gemm_set_terms: terms must be 1, 3 or 6 (got %d)", terms);
+  g_gemm_terms = terms;
+  return 0;
+}
+
+// ---- operator-level batched mat-mul: Y[T][rows] = X[T][cols] W^T ----------------------------------------------------
+// T < 8 (or an FP32 matrix): T GEMV launches, each bit-identical to tl_matvec_q. Otherwise the MFMA kernel above with
+// the process-wide term count (tl_gemm_set_terms); the activation planes live in a lazily grown workspace, so
+// concurrent calls on different streams must not share it (one host thread per stream, as in the reference).
+extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream) {
+  TL_REQUIRE(w && x_dev && y_dev && num_tokens >= 0, "tl_matmul_q: bad argument");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (num_tokens < 8 || w->type == TL_F32) {
+    for (int t = 0; t < num_tokens; ++t)
+      TL_TRY(tl_matvec_q(w, x_dev + (size_t)t * w->cols, y_dev + (size_t)t * w->rows, stream));
+    return 0;
+  }
+  static void* ws = nullptr;
+  static size_t ws_bytes = 0;
+  const int terms = g_gemm_terms, np = planes_of_terms(terms);
+  const size_t ps = tl_gemm_padded_tokens(num_tokens) * (size_t)w->cols, need = ps * np * sizeof(__bf16);
+  if (need > ws_bytes) {
+    TL_HIP(hipDeviceSynchronize());
+    if (ws) TL_HIP(hipFree(ws));
+    ws = nullptr;
+    ws_bytes = 0;
+    TL_HIP(hipMalloc(&ws, need));
+    TL_HIP(hipMemsetAsync(ws, 0, need, s));
+    ws_bytes = need;
+  }
+  TL_TRY(tl_launch_split(SPLIT_PLAIN, x_dev, nullptr, ws, ps, num_tokens, w->cols, terms, 0.f, s));
+  return tl_launch_gemm_q(qw_view(w), ws, ps, y_dev, nullptr, num_tokens, terms, s);
+}

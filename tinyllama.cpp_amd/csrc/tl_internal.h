@@ -98,6 +98,7 @@ int tl_launch_rmsnorm(const float* x, const float* w, float* out, int T, int n, 
                       hipStream_t s);
 int tl_launch_dequant_rows(const tl_qweight* w, const int* row_index_dev, int row0, int nrows, float* out,
                            hipStream_t s);
+int tl_launch_dequant_gather(const tl_qweight* w, const int* ids_dev, int n, float* out, hipStream_t s);
 int tl_launch_rope_kv(float* q, float* k, const float* v, float* kcache, float* vcache, const float* table, int nq,
                       int nkv, int hd, const int* pos_dev, int max_pos, hipStream_t s);
 int tl_launch_attn_decode(const float* q, const float* kc, const float* vc, float* out, int nh, int nkv, int hd,
@@ -129,6 +130,21 @@ bool tl_attn_split_supported(int nh, int nkv, int hd);
 size_t tl_attn_ws_floats(int nh, int hd);
 int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s);
 int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s);
+
+// batched-prefill GEMM on the matrix cores (tl_gemm.hip): activation planes = the FP32 activations split into
+// 1..3 bf16 planes [plane][padded tokens][cols]; terms = MFMAs per product (1, 3 or 6)
+int tl_gemm_default_terms();
+size_t tl_gemm_padded_tokens(int T);
+// mode 0: planes = split(x[T][K]); 1: split(rmsnorm_batch(x, aux = weight[K], eps)); 2: split(swiglu(x, aux[T][K]))
+int tl_launch_split(int mode, const float* x, const float* aux, void* planes, size_t plane_stride, int T, int K,
+                    int terms, float eps, hipStream_t s);
+int tl_launch_gemm_q(const QW& w, const void* planes, size_t plane_stride, float* y, const float* resid, int T,
+                     int terms, hipStream_t s);
+
+// causal prefill attention on the FP32 matrix instruction (tl_prefill.hip)
+bool tl_attn_prefill_mfma_supported(int nh, int nkv, int hd);
+int tl_launch_attn_prefill_mfma(const float* q, const float* kc, const float* vc, float* out, int T, int start_pos,
+                                int nh, int nkv, int hd, float scale, hipStream_t s);
 
 int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, const int* n_hist_dev, float penalty,
                      hipStream_t s);

@@ -70,6 +70,18 @@ struct tl_model {
   bool finalized = false;
   bool no_graph = false;  // TL_NO_GRAPH=1: replay steps eagerly (profilers that cannot follow graph launches)
   double weight_bytes = 0.0;  // algorithmic (GGUF) bytes of all per-token matrices incl. one embedding row
+  // batched prefill (MFMA GEMMs over a chunk of tokens): workspaces, allocated at the first batched call
+  struct Prefill {
+    int cap = 0;               // tokens per chunk the buffers hold
+    float *xb = nullptr, *qb = nullptr, *kb = nullptr, *vb = nullptr, *ab = nullptr, *gb = nullptr, *ub = nullptr;
+    void* planes = nullptr;    // bf16 [3][plane_stride]
+    size_t plane_stride = 0;
+    float* logits_all = nullptr;  // [cap][vocab], only when all logits were asked for
+    int* toks = nullptr;
+    int toks_cap = 0;
+  } pf;
+  int prefill_terms = 0;     // MFMAs per product in the prefill GEMMs (0: tl_gemm_set_terms' process-wide value)
+  int prefill_min_batch = 8; // prompts shorter than this replay the decode graph token by token
   float* kc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems; }
   float* vc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems + kv_layer_elems; }
 };
@@ -150,6 +162,10 @@ extern "C" int tl_model_free(tl_model* m) {
   hipFree(m->cand_v);
   hipFree(m->cand_i);
   hipFree(m->attn_ws);
+  float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all};
+  for (float* b : pbufs) hipFree(b);
+  hipFree(m->pf.planes);
+  hipFree(m->pf.toks);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -751,10 +767,116 @@ extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_
   return 0;
 }
 
-// Batched prefill. This build runs the T prompt tokens as T replays of the decode graph (token ids fed from the
-// host-provided list); positions, KV contents and logits are those of the token-by-token path, which the
-// reference's batched CPU path reproduces to ~1e-6.
+// ---- batched prefill (forward_device_batch_prefill model.cpp:1526-1862; math of CPUBatchProcessor::forward_cpu_batch,
+//      cpu_batch_processor.cpp:11-281) -----------------------------------------------------------------------------------
+// A chunk of up to kPrefillChunk tokens goes through every layer as a batch: RMSNorm -> bf16 planes, q/k/v GEMMs on
+// the matrix cores (tl_gemm.hip), batched RoPE + KV write, causal attention from the cache (tl_prefill.hip), O GEMM +
+// residual, RMSNorm -> planes, gate/up GEMMs, SwiGLU -> planes, down GEMM + residual. Longer prompts are walked chunk by
+// chunk over the growing cache. Short prompts (< prefill_min_batch) and tensor-parallel shards replay the decode graph
+// token by token instead (same positions, KV contents and logits to ~1e-6).
+constexpr int kPrefillChunk = 512;
+
 __global__ void set_token_kernel(int* state, const int* tokens, int i) { state[0] = tokens[i]; }
+
+static int ensure_prefill_ws(tl_model* m, bool all_logits) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  if (p.cap == 0) {
+    const int cap = c.max_position_embeddings < kPrefillChunk ? c.max_position_embeddings : kPrefillChunk;
+    const size_t H = c.hidden_size, maxk = H > (size_t)m->I_l ? H : (size_t)m->I_l;
+    const size_t kmax = maxk > (size_t)m->qd_l ? maxk : (size_t)m->qd_l;
+    p.plane_stride = tl_gemm_padded_tokens(cap) * kmax;
+    TL_HIP(hipMalloc(&p.xb, sizeof(float) * cap * H));
+    TL_HIP(hipMalloc(&p.qb, sizeof(float) * cap * (size_t)m->qd_l));
+    TL_HIP(hipMalloc(&p.kb, sizeof(float) * cap * (size_t)m->kv_dim));
+    TL_HIP(hipMalloc(&p.vb, sizeof(float) * cap * (size_t)m->kv_dim));
+    TL_HIP(hipMalloc(&p.ab, sizeof(float) * cap * (size_t)m->qd_l));
+    TL_HIP(hipMalloc(&p.gb, sizeof(float) * cap * (size_t)m->I_l));
+    TL_HIP(hipMalloc(&p.ub, sizeof(float) * cap * (size_t)m->I_l));
+    TL_HIP(hipMalloc(&p.planes, 2 * 3 * p.plane_stride));
+    TL_HIP(hipMemsetAsync(p.planes, 0, 2 * 3 * p.plane_stride, m->stream));
+    p.cap = cap;
+  }
+  if (all_logits && !p.logits_all) TL_HIP(hipMalloc(&p.logits_all, sizeof(float) * p.cap * (size_t)c.vocab_size));
+  return 0;
+}
+
+// one chunk: tokens toks_dev[0..T) at positions start_pos.., T <= pf.cap; leaves the residual stream in pf.xb
+static int enqueue_prefill_chunk(tl_model* m, const int* toks_dev, int T, int start_pos) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  hipStream_t s = m->stream;
+  const int H = c.hidden_size, hd = m->head_dim;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  const size_t ps = p.plane_stride;
+  const float scale = 1.0f / sqrtf((float)hd);
+  TL_TRY(tl_launch_dequant_gather(m->tok, toks_dev, T, p.xb, s));
+  for (int l = 0; l < c.num_hidden_layers; ++l) {
+    LayerW& L = m->layers[l];
+    TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, s));
+    TL_TRY(tl_rope_batch(p.qb, p.kb, m->rope, T, m->nh_l, m->nkv_l, hd, start_pos, c.max_position_embeddings, 1, s));
+    TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+    TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+    TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
+                                      m->nkv_l, hd, scale, s));
+    TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s));
+    TL_TRY(tl_launch_split(1, p.xb, L.ffn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, s));
+    TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_DOWN]), p.planes, ps, p.xb, p.xb, T, terms, s));
+  }
+  return 0;
+}
+
+static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
+                           float* all_logits_host) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  hipStream_t s = m->stream;
+  TL_TRY(ensure_prefill_ws(m, all_logits_host != nullptr));
+  if (p.toks_cap < num_tokens) {
+    if (p.toks) TL_HIP(hipFree(p.toks));
+    p.toks = nullptr;
+    p.toks_cap = 0;
+    TL_HIP(hipMalloc(&p.toks, sizeof(int) * (size_t)num_tokens));
+    p.toks_cap = num_tokens;
+  }
+  TL_HIP(hipMemcpyAsync(p.toks, tokens_host, sizeof(int) * (size_t)num_tokens, hipMemcpyHostToDevice, s));
+  const size_t H = c.hidden_size, V = c.vocab_size;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  for (int c0 = 0; c0 < num_tokens; c0 += p.cap) {
+    const int T = num_tokens - c0 < p.cap ? num_tokens - c0 : p.cap;
+    TL_TRY(enqueue_prefill_chunk(m, p.toks + c0, T, start_pos + c0));
+    if (all_logits_host) {  // final norm + lm_head for every token of the chunk (forward_cpu_logits_batch, model.cpp:1094-1156)
+      TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, (int)H, terms, c.rms_norm_eps, s));
+      TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
+      TL_HIP(hipMemcpyAsync(all_logits_host + (size_t)c0 * V, p.logits_all, sizeof(float) * (size_t)T * V,
+                            hipMemcpyDeviceToHost, s));
+    }
+    if (c0 + T == num_tokens) {  // logits of the last token through the decode step's fused norm + lm_head GEMV
+      TL_HIP(hipMemcpyAsync(m->x, p.xb + (size_t)(T - 1) * H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+      TL_TRY(enqueue_head(m, s));
+      if (last_logits_host)
+        TL_HIP(hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, s));
+    }
+  }
+  TL_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+extern "C" int tl_model_set_prefill(tl_model* m, int terms, int min_batch) {
+  TL_REQUIRE(m, "tl_model_set_prefill: null model");
+  TL_REQUIRE(terms == 0 || terms == 1 || terms == 3 || terms == 6, "tl_model_set_prefill: terms must be 0, 1, 3 or 6 (got %d)", terms);
+  TL_REQUIRE(min_batch >= 1, "tl_model_set_prefill: min_batch must be >= 1");
+  m->prefill_terms = terms;
+  m->prefill_min_batch = min_batch;
+  return 0;
+}
 
 extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos,
                                 float* last_logits_host, float* all_logits_host) {
@@ -764,6 +886,8 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m->cfg.max_position_embeddings,
              "tl_model_prefill: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + num_tokens,
              m->cfg.max_position_embeddings);
+  if (m->tp == 1 && num_tokens >= m->prefill_min_batch)
+    return prefill_batched(m, tokens_host, num_tokens, start_pos, last_logits_host, all_logits_host);
   int* toks_dev = nullptr;
   TL_HIP(hipMalloc(&toks_dev, sizeof(int) * (size_t)num_tokens));
   hipError_t e = hipMemcpyAsync(toks_dev, tokens_host, sizeof(int) * (size_t)num_tokens, hipMemcpyHostToDevice, m->stream);
@@ -864,11 +988,3 @@ extern "C" int tl_model_tp_init(tl_model* m, const void* unique_id_128) {
   return 0;
 }
 
-// ---- operator-level batched mat-mul (prefill): Y[T][rows] = X[T][cols] W^T ----------------------------------
-// This build runs it as T GEMV launches over the quantized weights (each bit-identical to tl_matvec_q).
-extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream) {
-  TL_REQUIRE(w && x_dev && y_dev && num_tokens >= 0, "tl_matmul_q: bad argument");
-  for (int t = 0; t < num_tokens; ++t)
-    TL_TRY(tl_matvec_q(w, x_dev + (size_t)t * w->cols, y_dev + (size_t)t * w->rows, stream));
-  return 0;
-}

@@ -403,6 +403,9 @@ extern "C" int tl_attention_batch_prefill(const float* q_batch_dev, const float*
   TL_REQUIRE(head_dim > 0 && head_dim <= 256 && num_kv_heads > 0 && num_q_heads % num_kv_heads == 0,
              "tl_attention_batch_prefill: bad head configuration");
   if (num_tokens == 0) return 0;
+  if (tl_attn_prefill_mfma_supported(num_q_heads, num_kv_heads, head_dim))  // tiled, any context length
+    return tl_launch_attn_prefill_mfma(q_batch_dev, k_cache_dev, v_cache_dev, out_batch_dev, num_tokens, start_pos,
+                                       num_q_heads, num_kv_heads, head_dim, scale, static_cast<hipStream_t>(stream));
   const size_t lds = sizeof(float) * (32 + 4 * (size_t)head_dim + (size_t)(start_pos + num_tokens));
   TL_REQUIRE(lds <= 160 * 1024, "tl_attention_batch_prefill: sequence too long for LDS scores (%zu B)", lds);
   static bool attr = false;

@@ -259,15 +259,24 @@ __device__ inline float half_bits_to_float(uint32_t h, bool scale_field) {
   return __uint_as_float(bits);
 }
 
+// row of output line lr: row0 + lr; with row_index: row_index[0] + lr, or (gather) row_index[lr], where an id outside
+// the table yields a zero line (lookup_embedding, model_utils.cpp:15-19)
 __global__ void dequant_rows_kernel(QW w, const int* __restrict__ row_index, int row0, int nrows,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int gather) {
 #pragma clang fp contract(off)
   const int cpr = w.cols >> 5;  // chunks per row
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)nrows * cpr) return;
   const int lr = (int)(gid / cpr), cc = (int)(gid % cpr);
-  int row = row_index ? row_index[0] + lr : row0 + lr;
-  if (row < 0 || row >= w.rows) row = 0;  // callers validate; never read out of bounds
+  int row = row_index ? (gather ? row_index[lr] : row_index[0] + lr) : row0 + lr;
+  if (row < 0 || row >= w.rows) {
+    if (gather) {
+      float4* z = reinterpret_cast<float4*>(out + ((size_t)lr * cpr + cc) * 32);
+      for (int i = 0; i < 8; ++i) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      return;
+    }
+    row = 0;  // callers validate; never read out of bounds
+  }
   const size_t c = (size_t)row * cpr + cc;  // global chunk index
   float y[32];
   switch (w.type) {
@@ -332,7 +341,16 @@ int tl_launch_dequant_rows(const tl_qweight* w, const int* row_index_dev, int ro
                            hipStream_t s) {
   const size_t n = (size_t)nrows * (w->cols / 32);
   if (n == 0) return 0;
-  dequant_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(qw_view(w), row_index_dev, row0, nrows, out);
+  dequant_rows_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(qw_view(w), row_index_dev, row0, nrows, out, 0);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[i][:] = dequantized row ids_dev[i] of the table, i < n (batched embedding lookup)
+int tl_launch_dequant_gather(const tl_qweight* w, const int* ids_dev, int n, float* out, hipStream_t s) {
+  const size_t total = (size_t)n * (w->cols / 32);
+  if (total == 0) return 0;
+  dequant_rows_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(qw_view(w), ids_dev, 0, n, out, 1);
   TL_HIP(hipGetLastError());
   return 0;
 }

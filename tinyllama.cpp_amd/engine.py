@@ -202,6 +202,11 @@ class Model:
               "tl_model_generate_greedy")
         return out[:n_steps]
 
+    def set_prefill(self, terms=0, min_batch=8):
+        """bf16 MFMAs per FP32 product in the batched-prefill GEMMs (6 default / 3 / 1; 0 = process-wide value) and the
+        prompt length from which tl_model_prefill runs batched."""
+        check(lib().tl_model_set_prefill(self.h, int(terms), int(min_batch)), "tl_model_set_prefill")
+
     def prefill(self, tokens, start_pos=0, all_logits=False):
         toks = np.ascontiguousarray(tokens, np.int32)
         last = np.empty(self.cfg["vocab"], np.float32)

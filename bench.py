@@ -197,6 +197,10 @@ def main():
         "load_s": round(t_load, 1),
     }
 
+    # ---- batched prefill on the matrix cores (outside the timed decode region): 512 prompt tokens, FP32-grade 6-term form
+    if world == 1 and cfg["max_pos"] >= 512 + 8:
+        out["prefill"] = prefill_leg(model, S, cfg, mix, 512)
+
     # ---- CPU baseline: the oracle in the reference's structure on a bounded sample ------------------------------
     if want_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg, keep, args.cpu_layers, w_bytes)
@@ -204,6 +208,28 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3):
+    """tokens/s of tl_model_prefill (MFMA GEMMs over the quantized weights, FP32-MFMA attention) for a T-token prompt;
+    executed bf16 MFMA flops = terms x the algorithmic GEMM flops 2*T*(layer weight elements)."""
+    toks = np.random.default_rng(1).integers(0, cfg["vocab"], T).astype(np.int32)
+    model.set_prefill(terms=terms, min_batch=8)
+    model.reset_kv()
+    model.prefill(toks, 0)
+    best = 1e9
+    for _ in range(reps):
+        model.reset_kv()
+        t0 = time.perf_counter()
+        model.prefill(toks, 0)
+        best = min(best, time.perf_counter() - t0)
+    elems = sum(r * c for n, t, r, c in S.tensor_plan(cfg, mix) if n.startswith("blk.") and t != S.F32)
+    flops = 2.0 * T * elems
+    return {"prompt_tokens": T, "mfma_terms": terms, "ms": round(best * 1e3, 2), "tokens_per_s": round(T / best, 1),
+            "gemm_tflops_algorithmic": round(flops / best / 1e12, 1),
+            "bf16_mfma_tflops_executed": round(flops * terms / best / 1e12, 1),
+            "frac_of_bf16_dense_peak": round(flops * terms / best / 2.5e15, 4),
+            "note": "whole prefill wall time incl. attention and glue; per-kernel MFMA busy counters: profiles/"}
 
 
 def cpu_baseline(cfg, keep, n_layers, w_bytes):

@@ -1,0 +1,56 @@
+/* tlhost.h — C view of the C++ host layer (tinyllama.cpp_amd/host, libtlhost.so) that sits above tlhip.h.
+ *
+ * The host layer itself is C++ (tl_gguf.hpp: GGUF reader replacing gguf_parser.cpp:123-806 for this backend;
+ * tl_session.hpp: tlhost::Session mirroring tinyllama::TinyLlamaSession, api.h:26-143, on token ids). These entry points
+ * exist so that the repository's Python tests (and any other FFI) can drive it; a C++ host links the classes directly.
+ * Every function returns 0 on success; tlh_last_error() has the text (the C++ layer throws std::runtime_error). */
+#ifndef TLHOST_H
+#define TLHOST_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* tlh_last_error(void);
+
+/* ---- GGUF reader (no GPU involved) : load_gguf_meta, gguf_parser.cpp:123 ---- */
+typedef struct tlh_gguf tlh_gguf;
+int tlh_gguf_open(const char* path, tlh_gguf** out);
+int tlh_gguf_close(tlh_gguf* g);
+int tlh_gguf_counts(const tlh_gguf* g, uint64_t* n_tensors, uint64_t* n_metadata, uint64_t* alignment);
+/* tensor i: name copied into name_buf (NUL-terminated, truncated to buf_len), ggml type, dims[4] (unused = 1), offset
+ * relative to the data section, byte size, and a pointer to the bytes inside the mapping (valid until close) */
+int tlh_gguf_tensor(const tlh_gguf* g, uint64_t i, char* name_buf, size_t buf_len, uint32_t* type, uint64_t dims[4],
+                    uint32_t* n_dims, uint64_t* offset, uint64_t* nbytes, const void** data);
+/* metadata lookups: *found = 0 when the key is absent or of another kind */
+int tlh_gguf_meta_int(const tlh_gguf* g, const char* key, int64_t* value, int* found);
+int tlh_gguf_meta_float(const tlh_gguf* g, const char* key, double* value, int* found);
+int tlh_gguf_meta_string(const tlh_gguf* g, const char* key, char* buf, size_t buf_len, int* found);
+/* the model configuration as parse_model_config_from_gguf derives it (model_config.cpp:149-221):
+ * out[0..8] = hidden, intermediate, heads, kv heads, layers, vocab, context, bos id, eos id; eps_theta[0..1] */
+int tlh_gguf_model_config(const tlh_gguf* g, int out[9], float eps_theta[2]);
+
+/* ---- session : TinyLlamaSession (api.h:42-78) on token ids ---- */
+typedef struct tlh_session tlh_session;
+int tlh_session_open(const char* gguf_path, int device, int max_context, tlh_session** out);
+int tlh_session_close(tlh_session* s);
+int tlh_session_set_repetition_penalty(tlh_session* s, float penalty);
+int tlh_session_seed(tlh_session* s, uint32_t seed);
+/* generate(): writes up to out_cap generated ids (prompt excluded), *n_out = how many */
+int tlh_session_generate(tlh_session* s, const int* prompt_ids, int n_prompt, int steps, float temperature, int top_k,
+                         float top_p, int* out_ids, int out_cap, int* n_out);
+/* load statistics: tensors uploaded, quantized bytes taken from the mapping, seconds for open() */
+int tlh_session_load_stats(const tlh_session* s, uint64_t* tensors, uint64_t* quantized_bytes, double* seconds);
+
+/* ---- host-side sampler pieces (api.cpp:86-97, 126-216), exposed for parity tests; no GPU involved ---- */
+int tlh_apply_repetition_penalty(float* logits, int n, const int* generated, int n_generated, float penalty);
+/* candidate ids and renormalised probabilities the sampler draws from; *n_out <= cap entries written */
+int tlh_sampling_distribution(const float* logits, int n, float temperature, int top_k, float top_p, int* ids,
+                              float* probs, int cap, int* n_out);
+int tlh_sample(const float* logits, int n, float temperature, int top_k, float top_p, uint32_t seed, int* id_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+"""CPU-side checks of the C++ host layer (libtlhost.so): the GGUF reader against files written by synth.write_gguf
+(byte-for-byte tensor payloads, metadata, derived model configuration, malformed files), the host-side sampler pieces
+against a numpy restatement of api.cpp:86-216, and the exported-symbol surface of include/tlhost.h. No GPU calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def H(pkg):
+    from tinyllama_cpp_amd import hostapi
+    hostapi.lib()
+    return hostapi
+
+
+def declared():
+    text = open(os.path.join(ROOT, "include", "tlhost.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tlh_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(H):
+    L = ctypes.CDLL(H.LIB_PATH)
+    syms = declared()
+    assert len(syms) >= 17
+    for s in syms:
+        assert hasattr(L, s), f"{s} is declared in include/tlhost.h but not exported"
+    assert sorted(list(H.SIGNATURES) + ["tlh_last_error"]) == syms
+
+
+@pytest.mark.parametrize("shape,mix", [("tiny", "q4_k_m"), ("tiny-gqa", "q6_k"), ("tiny", "q8_0")])
+def test_gguf_reader_roundtrip(H, pkg, tmp_path, shape, mix):
+    S = pkg.synth
+    cfg, tensors = S.build_model(shape, mix, seed=7)
+    path = S.write_gguf(str(tmp_path / "m.gguf"), cfg, tensors)
+    g = H.GGUF(path)
+    nt, nm, al = g.counts()
+    assert nt == len(tensors) and al == 32 and nm == 14
+    for i, (name, (typ, arr, rows, cols)) in enumerate(tensors.items()):
+        gname, gtyp, dims, off, raw = g.tensor(i)
+        assert gname == name and gtyp == typ
+        assert dims == ([cols] if typ == S.F32 and rows == 1 else [cols, rows])
+        assert off % 32 == 0
+        assert np.array_equal(raw, np.ascontiguousarray(arr).view(np.uint8).ravel()), name
+    assert g.meta_string("general.architecture") == "llama"
+    assert g.meta_int("llama.block_count") == cfg["n_layers"]
+    assert g.meta_int("general.architecture") is None and g.meta_int("no.such.key") is None
+    assert abs(g.meta_float("llama.rope.freq_base") - cfg["rope_theta"]) < 1e-3
+    mc = g.model_config()
+    for k in ("hidden", "inter", "n_heads", "n_kv_heads", "n_layers", "vocab", "max_pos"):
+        assert mc[k] == cfg[k], k
+    assert mc["bos"] == 1 and mc["eos"] == 2 and abs(mc["eps"] - cfg["eps"]) < 1e-12
+    g.close()
+
+
+def test_gguf_reader_rejects_malformed_files(H, pkg, tmp_path):
+    S = pkg.synth
+    cfg, tensors = S.build_model("tiny", "q8_0", seed=1)
+    path = S.write_gguf(str(tmp_path / "m.gguf"), cfg, tensors)
+    blob = open(path, "rb").read()
+    cases = {"magic": b"XGUF" + blob[4:], "truncated_header": blob[:40], "truncated_data": blob[: len(blob) // 2],
+             "empty": b""}
+    for tag, data in cases.items():
+        p = str(tmp_path / f"{tag}.gguf")
+        open(p, "wb").write(data)
+        with pytest.raises(H.TlHostError):
+            H.GGUF(p)
+    with pytest.raises(H.TlHostError):
+        H.GGUF(str(tmp_path / "missing.gguf"))
+    # context lengths outside (0, 8192] fall back to 2048 (model_config.cpp: llama.context_length)
+    big = dict(cfg, max_pos=100000)
+    g = H.GGUF(S.write_gguf(str(tmp_path / "big.gguf"), big, tensors))
+    assert g.model_config()["max_pos"] == 2048
+    g.close()
+
+
+def _distribution(logits, temperature, top_k, top_p):
+    """numpy restatement of api.cpp:138-210: double softmax of (l - max)/T rounded to float, descending sort by
+    (prob, id), top-k cut, float cumulative sum until >= top_p, float renormalisation."""
+    V = logits.size
+    top_k = V if top_k <= 0 else min(top_k, V)
+    scaled = ((logits - logits.max()) * np.float32(1.0 / np.float32(temperature))).astype(np.float32)
+    e = np.exp(scaled.astype(np.float64))
+    p = (e / e.sum()).astype(np.float32)
+    order = sorted(range(V), key=lambda i: (p[i], i), reverse=True)[:top_k]
+    cum, keep = np.float32(0), len(order)
+    for n, i in enumerate(order):
+        cum = np.float32(cum + p[i])
+        if cum >= np.float32(top_p):
+            keep = n + 1
+            break
+    order = order[:keep]
+    tot = np.float32(0)
+    for i in order:
+        tot = np.float32(tot + p[i])
+    return np.array(order, np.int32), np.array([p[i] / tot for i in order], np.float32)
+
+
+def test_sampler_pieces_match_restatement(H):
+    rng = np.random.default_rng(0)
+    for V, T, k, pp in ((1000, 0.8, 40, 0.9), (257, 1.5, 0, 0.5), (64, 0.1, 5, 0.99), (5000, 1.0, 5000, 1.0),
+                        (100, 0.7, 1000, 0.0)):
+        logits = (rng.standard_normal(V) * 3).astype(np.float32)
+        logits[3] = logits[7]  # equal probabilities: the higher id sorts first
+        ids, probs = H.sampling_distribution(logits, T, k, pp)
+        wi, wp = _distribution(logits, T, k, pp)
+        assert np.array_equal(ids, wi), (V, T, k, pp)
+        assert np.allclose(probs, wp, rtol=1e-6, atol=0)
+        assert abs(float(probs.sum()) - 1.0) < 1e-5
+    logits = (rng.standard_normal(300) * 2).astype(np.float32)
+    assert H.sample(logits, 0.01, 40, 0.9, seed=5) == int(np.argmax(logits))  # temperature < 0.05: greedy
+    assert H.sample(logits, 0.8, 1, 0.9, seed=5) == int(np.argmax(logits))   # top-k 1
+    draws = [H.sample(logits, 1.0, 10, 1.0, seed=s) for s in range(200)]
+    top10 = set(np.argsort(-logits)[:10].tolist())
+    assert set(draws) <= top10 and len(set(draws)) > 3
+    assert H.sample(logits, 1.0, 10, 1.0, seed=42) == H.sample(logits, 1.0, 10, 1.0, seed=42)
+    # repetition penalty: last 64 generated ids, l > 0 ? l / p : l * p, repeated ids penalised repeatedly
+    gen = np.concatenate([rng.integers(0, 300, 100), [5, 5, 299, -1, 1000]]).astype(np.int32)
+    want = logits.copy()
+    for t in gen[-64:]:
+        if 0 <= t < 300:
+            want[t] = want[t] / np.float32(1.3) if want[t] > 0 else want[t] * np.float32(1.3)
+    assert np.array_equal(H.apply_repetition_penalty(logits, gen, 1.3), want)
+    assert np.array_equal(H.apply_repetition_penalty(logits, gen, 1.0), logits)
+    assert np.array_equal(H.apply_repetition_penalty(logits, [], 1.3), logits)

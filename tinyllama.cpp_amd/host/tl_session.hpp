@@ -1,0 +1,71 @@
+// tl_session.hpp — the C++ host above the C-ABI (include/tlhip.h): what TinyLlamaSession / TinyLlamaModel keep doing on
+// the host once the CUDA backend is replaced by libtlhip.so.
+//
+// Mirrors tinyllama::TinyLlamaSession (api.h:26-143) on TOKEN IDS: the tokenizer (tokenizer.cpp, needs Boost) is out of
+// scope, so generate() takes and returns ids where the reference takes and returns text. Same argument meaning
+// (steps, temperature, top_k, top_p), same loop (api.cpp:585-813), same error convention (std::runtime_error).
+#pragma once
+#include <cstdint>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "tl_gguf.hpp"
+#include "tlhip.h"
+
+namespace tlhost {
+
+// what parse_model_config_from_gguf reads (model_config.cpp:149-221)
+struct ModelConfig {
+  int hidden_size = 0, intermediate_size = 0, num_attention_heads = 0, num_key_value_heads = 0, num_hidden_layers = 0;
+  int vocab_size = 32000, max_position_embeddings = 2048;
+  float rms_norm_eps = 1e-5f, rope_theta = 10000.0f;
+  int bos_token_id = 1, eos_token_id = 2;
+  std::string architecture, name;
+};
+ModelConfig config_from_gguf(const GGUFFile& f);
+
+struct LoadStats {
+  size_t tensors = 0, quantized_bytes = 0;
+  double seconds = 0.0;
+};
+
+class Session {
+ public:
+  // model_path: a .gguf file. device: HIP device ordinal. max_context > 0 caps the KV cache length below the file's
+  // context length. tp_rank / tp_size: tensor-parallel shard (the caller wires the communicator through model()).
+  explicit Session(const std::string& model_path, int device = 0, int max_context = 0);
+  ~Session();
+  Session(const Session&) = delete;
+  Session& operator=(const Session&) = delete;
+
+  // TinyLlamaSession::generate on ids: returns the generated ids (prompt excluded). temperature < 0.05 is greedy
+  // (api.cpp:134) and runs entirely on the device; otherwise top-k / top-p sampling on the logits (api.cpp:126-216).
+  std::vector<int> generate(const std::vector<int>& prompt_ids, int steps = 128, float temperature = 0.1f, int top_k = 40,
+                            float top_p = 0.9f);
+
+  void set_repetition_penalty(float p) { repetition_penalty_ = p; }
+  float get_repetition_penalty() const { return repetition_penalty_; }
+  void seed(uint32_t s) { rng_.seed(s); }
+  const ModelConfig& get_config() const { return config_; }
+  const LoadStats& load_stats() const { return stats_; }
+  tl_model* model() { return model_; }
+
+ private:
+  ModelConfig config_;
+  tl_model* model_ = nullptr;
+  std::mt19937 rng_{std::random_device{}()};
+  float repetition_penalty_ = 1.3f;  // api.h:135
+  LoadStats stats_;
+};
+
+// api.cpp:86-97 and :126-216 on the host (used on the non-greedy path, where the logits come back from the device)
+void apply_repetition_penalty(std::vector<float>& logits, const std::vector<int>& generated, float penalty,
+                              size_t window = 64);
+int sample_top_k_top_p_temperature(const std::vector<float>& logits, float temperature, int top_k, float top_p,
+                                   std::mt19937& rng);
+// the candidate set and renormalised probabilities the sampler draws from (exposed for tests)
+void sampling_distribution(const std::vector<float>& logits, float temperature, int top_k, float top_p,
+                           std::vector<int>* ids, std::vector<float>* probs);
+
+}  // namespace tlhost

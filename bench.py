@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--workload", default="llama-3-8b")
     ap.add_argument("--mix", default=None)
     ap.add_argument("--max-pos", type=int, default=2048, help="KV-cache length allocated for the run")
+    ap.add_argument("--no-prefill-leg", action="store_true")
     ap.add_argument("--prompt-len", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2, help="layers in the CPU-baseline sample")
@@ -120,8 +121,11 @@ def main():
     # ---- prompt (token by token: P < 32), then warm-up and the timed region --------------------------------
     prompt = np.random.default_rng(0).integers(0, cfg["vocab"], args.prompt_len)
     nxt = 0
-    for pos, tok in enumerate(prompt):
-        _, nxt = model.decode(int(tok), pos, want_logits=False)
+    if len(prompt) >= 32 and world == 1:  # the generate loop's rule (api.cpp:601): batched prefill from 32 tokens on
+        nxt = int(np.argmax(model.prefill(prompt.astype(np.int32), 0)))
+    else:
+        for pos, tok in enumerate(prompt):
+            _, nxt = model.decode(int(tok), pos, want_logits=False)
     pos = len(prompt)
     if args.warmup > 0:
         ids = model.generate_greedy(nxt, pos, args.warmup)
@@ -198,7 +202,7 @@ def main():
     }
 
     # ---- batched prefill on the matrix cores (outside the timed decode region): 512 prompt tokens, FP32-grade 6-term form
-    if world == 1 and cfg["max_pos"] >= 512 + 8:
+    if world == 1 and cfg["max_pos"] >= 512 + 8 and not args.no_prefill_leg:
         out["prefill"] = prefill_leg(model, S, cfg, mix, 512)
 
     # ---- CPU baseline: the oracle in the reference's structure on a bounded sample ------------------------------

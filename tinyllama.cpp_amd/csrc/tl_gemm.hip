@@ -18,9 +18,9 @@
 //     at 1/6 of the bf16 rate the 6-term form is still ~2.7x the chip's FP32 MFMA/VALU rate;
 //   - the activation planes are produced ONCE per GEMM input by the producer kernel (RMSNorm, SwiGLU or a plain
 //     split, below), not by every workgroup that consumes them;
-//   - tile: 128 tokens x 64 weight rows x 32 columns per step, 4 waves (each 64 tokens x 32 rows = two 32x32
-//     accumulators); LDS rows are padded to 80 B so that the 16 B/lane fragment reads are bank-conflict free; the
-//     next step's global loads are issued before the current step's MFMAs (register prefetch);
+//   - tile: 128 tokens x 64 or 128 weight rows x 32 columns per step, 4 waves (each 64 tokens x 32 or 64 rows = two
+//     or four 32x32 accumulators); XOR-swizzled 64-B LDS rows (fragment reads and staging writes bank-conflict free),
+//     two LDS buffers and one barrier per step, global loads two steps ahead in registers;
 //   - workgroup -> tile mapping is XCD-aware: the 8 XCDs (round-robin over blockIdx) each walk a contiguous range of
 //     weight-row tiles of ONE token panel, so a panel's activation planes (<= 3 MB) stay in that XCD's L2.
 #include <stdlib.h>
@@ -34,10 +34,8 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int GB_M = 64;    // weight rows per workgroup tile
 constexpr int GB_N = 128;   // tokens per workgroup tile
 constexpr int GB_K = 32;    // columns per step = one 32-weight chunk of the plane layout
-constexpr int GROW = 40;    // bf16 elements per LDS row (32 + 8 pad = 80 B)
 constexpr int GEMM_THREADS = 256;
 
 __device__ __forceinline__ float h2f(unsigned h) { return (float)__builtin_bit_cast(_Float16, (unsigned short)h); }
@@ -125,73 +123,109 @@ __device__ __forceinline__ void split8(const float* v, bf16x8* planes) {
   }
 }
 
-template <int TYPE, int NP, int NT>
+// BM = weight rows per workgroup tile (64 or 128): 4 waves as 2 (rows) x 2 (tokens), a wave owns 64 tokens x BM/2 rows
+// = 2 x BM/64 accumulators of 32x32.
+//
+// LDS image: rows of 32 bf16 (64 B, no padding), two buffers. The four 16-B chunks of a row are stored at chunk index
+// c ^ ((row >> 2) & 3): a 16-lane group of a fragment read (16 consecutive rows, one chunk) and of a staging write
+// (4 consecutive rows x 4 chunks) then both cover all 64 banks exactly once.
+// Pipeline per 32-column step, ONE barrier: write step k+1 (dequantized from the registers fetched a step earlier) into
+// the other buffer, fetch step k+2 into registers, run step k's MFMAs; the staging VALU work and the MFMAs of a wave are
+// independent instruction streams that the scheduler interleaves.
+constexpr int LROW = 32;
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * LROW + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+template <int NP, int BM>
+constexpr size_t gemm_lds_bytes() { return (size_t)2 * NP * (BM + GB_N) * LROW * sizeof(__bf16); }
+
+template <int TYPE, int NP, int NT, int BM>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
                                                               float* __restrict__ y, const float* __restrict__ resid,
                                                               int T, int mtiles, int ntiles) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ws[NP][GB_M * GROW];
-  __shared__ __attribute__((aligned(16))) __bf16 Xs[NP][GB_N * GROW];
+  constexpr int MI = BM / 64;  // 32-row weight fragments per wave, and staged (row, quarter) items per thread
+  constexpr int WPL = BM * LROW, XPL = GB_N * LROW;      // elements per plane
+  constexpr int BUF = NP * (WPL + XPL);                  // elements per buffer: W planes, then X planes
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   const int M = w.rows, K = w.cols;
   const int total = mtiles * ntiles;
   int tile = blockIdx.x;
   if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);  // contiguous range per XCD
   const int nt = tile / mtiles, mt = tile - nt * mtiles;
-  const int m0 = mt * GB_M, n0 = nt * GB_N;
+  const int m0 = mt * BM, n0 = nt * GB_N;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  // staging roles: weights (row, quarter of the chunk); activations: two 16-B pieces of the 128 x 64 B tile per plane
+  // staging roles: weights (row, quarter of the chunk), MI rows per thread; activations: two 16-B pieces of the
+  // 128 x 64 B tile per plane
   const int wrow = tid >> 2, wq = tid & 3;
-  const int grow = m0 + wrow < M ? m0 + wrow : M - 1;
+  int grow[MI];
+#pragma unroll
+  for (int j = 0; j < MI; ++j) grow[j] = m0 + wrow + 64 * j < M ? m0 + wrow + 64 * j : M - 1;
   const int xr0 = tid >> 2, xr1 = xr0 + 64, xs = tid & 3;
   const __bf16* xg0 = xp + (size_t)(n0 + xr0) * K + xs * 8;
   const __bf16* xg1 = xp + (size_t)(n0 + xr1) * K + xs * 8;
   const int nk = K / GB_K;
 
-  Raw8 rw = load8<TYPE>(w, grow, 0, wq);
+  Raw8 rw[MI];
   bf16x8 rx[NP][2];
+  auto fetch = [&](int kn) {  // global -> registers
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride);
-    rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride);
-  }
-  f32x16 acc[2];
+    for (int j = 0; j < MI; ++j) rw[j] = load8<TYPE>(w, grow[j], kn, wq);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int p = 0; p < NP; ++p) {
+      rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride + (size_t)kn * GB_K);
+      rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride + (size_t)kn * GB_K);
+    }
+  };
+  auto stage = [&](int buf, int kn) {  // registers (holding step kn) -> LDS buffer; weights dequantized + split on the way
+    __bf16* wb = lds + buf * BUF;
+    __bf16* xb = wb + NP * WPL;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-  const int fr = lane & 31, fh = lane >> 5;
-  for (int kk = 0; kk < nk; ++kk) {
-    {  // staged registers -> LDS (weights: dequantize + split on the way)
+    for (int j = 0; j < MI; ++j) {
       float wv[8];
-      deq8<TYPE>(rw, kk, wq, wv);
+      deq8<TYPE>(rw[j], kn, wq, wv);
       bf16x8 wp[NP];
       split8<NP>(wv, wp);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<bf16x8*>(&Ws[p][wrow * GROW + wq * 8]) = wp[p];
-        *reinterpret_cast<bf16x8*>(&Xs[p][xr0 * GROW + xs * 8]) = rx[p][0];
-        *reinterpret_cast<bf16x8*>(&Xs[p][xr1 * GROW + xs * 8]) = rx[p][1];
-      }
+      for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8*>(wb + p * WPL + lds_off(wrow + 64 * j, wq)) = wp[p];
     }
-    __syncthreads();
-    {  // next step's loads (the last step re-reads itself: unconditional, so the waits stay counted)
-      const int kn = kk + 1 < nk ? kk + 1 : kk;
-      rw = load8<TYPE>(w, grow, kn, wq);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride + (size_t)kn * GB_K);
-        rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride + (size_t)kn * GB_K);
-      }
+    for (int p = 0; p < NP; ++p) {
+      *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0, xs)) = rx[p][0];
+      *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr1, xs)) = rx[p][1];
     }
+  };
+  f32x16 acc[2][MI];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+  fetch(0);
+  stage(0, 0);
+  fetch(nk > 1 ? 1 : 0);
+  __syncthreads();
+  for (int kk = 0; kk < nk; ++kk) {
+    const int cur = kk & 1;
+    {  // step kk+1 into the other buffer, step kk+2 into registers (clamped at the end: unconditional, waits stay counted)
+      const int k1 = kk + 1 < nk ? kk + 1 : nk - 1, k2 = kk + 2 < nk ? kk + 2 : nk - 1;
+      stage(cur ^ 1, k1);
+      fetch(k2);
+    }
+    const __bf16* wb = lds + cur * BUF;
+    const __bf16* xb = wb + NP * WPL;
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
-      bf16x8 a[NP][2], b[NP];
+      bf16x8 a[NP][2], b[NP][MI];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        a[p][0] = *reinterpret_cast<const bf16x8*>(&Xs[p][(wn * 64 + fr) * GROW + k16 * 16 + fh * 8]);
-        a[p][1] = *reinterpret_cast<const bf16x8*>(&Xs[p][(wn * 64 + 32 + fr) * GROW + k16 * 16 + fh * 8]);
-        b[p] = *reinterpret_cast<const bf16x8*>(&Ws[p][(wm * 32 + fr) * GROW + k16 * 16 + fh * 8]);
+        a[p][0] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + fr, k16 * 2 + fh));
+        a[p][1] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 + fr, k16 * 2 + fh));
+#pragma unroll
+        for (int j = 0; j < MI; ++j)
+          b[p][j] = *reinterpret_cast<const bf16x8*>(wb + p * WPL + lds_off(wm * (BM / 2) + 32 * j + fr, k16 * 2 + fh));
       }
       // (x plane, w plane) pairs, smallest contributions first
       constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
@@ -199,14 +233,18 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16
       for (int t = 6 - NT; t < 6; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t] < NP ? PA[t] : 0][i], b[PB[t] < NP ? PB[t] : 0],
-                                                           acc[i], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t] < NP ? PA[t] : 0][i], b[PB[t] < NP ? PB[t] : 0][j],
+                                                                acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
   // D[token][row]: column (weight row) on the lane, token rows in the 16 registers
-  const int m = m0 + wm * 32 + fr;
-  if (m < M) {
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + wm * (BM / 2) + 32 * j + fr;
+    if (m >= M) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -214,7 +252,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16
         const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (t < T) {
           const size_t o = (size_t)t * M + m;
-          y[o] = resid ? resid[o] + acc[i][e] : acc[i][e];
+          y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
         }
       }
   }
@@ -260,16 +298,42 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 
 int planes_of_terms(int terms) { return terms == 1 ? 1 : terms == 3 ? 2 : 3; }
 
+template <int TYPE, int NP, int NT, int BM>
+int launch_gemm_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + GB_N - 1) / GB_N;
+  constexpr size_t lds = gemm_lds_bytes<NP, BM>();
+  static bool attr = false;  // per instantiation
+  if (!attr) {
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_kernel<TYPE, NP, NT, BM>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  gemm_q_kernel<TYPE, NP, NT, BM><<<dim3(mtiles * ntiles), dim3(GEMM_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int TYPE, int BM>
+int launch_gemm_bm(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
+                   hipStream_t s) {
+  if (terms == 1) return launch_gemm_inst<TYPE, 1, 1, BM>(w, xp, ps, y, resid, T, s);
+  if (terms == 3) return launch_gemm_inst<TYPE, 2, 3, BM>(w, xp, ps, y, resid, T, s);
+  return launch_gemm_inst<TYPE, 3, 6, BM>(w, xp, ps, y, resid, T, s);
+}
+
 template <int TYPE>
 int launch_gemm_typed(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                       hipStream_t s) {
-  const int mtiles = (w.rows + GB_M - 1) / GB_M, ntiles = (T + GB_N - 1) / GB_N;
-  const dim3 grid(mtiles * ntiles), block(GEMM_THREADS);
-  if (terms == 1) gemm_q_kernel<TYPE, 1, 1><<<grid, block, 0, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
-  else if (terms == 3) gemm_q_kernel<TYPE, 2, 3><<<grid, block, 0, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
-  else gemm_q_kernel<TYPE, 3, 6><<<grid, block, 0, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
-  TL_HIP(hipGetLastError());
-  return 0;
+  // 128-row tiles when they still give every CU two workgroups' worth of tiles, else 64-row tiles
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("TL_GEMM_BM");
+    forced = e ? atoi(e) : 0;
+  }
+  const long tiles128 = (long)((w.rows + 127) / 128) * ((T + GB_N - 1) / GB_N);
+  const bool big = forced ? forced == 128 : tiles128 >= 2 * 256;
+  return big ? launch_gemm_bm<TYPE, 128>(w, xp, ps, y, resid, T, terms, s)
+             : launch_gemm_bm<TYPE, 64>(w, xp, ps, y, resid, T, terms, s);
 }
 
 int g_gemm_terms = 6;

@@ -79,6 +79,9 @@ struct tl_model {
     float* logits_all = nullptr;  // [cap][vocab], only when all logits were asked for
     int* toks = nullptr;
     int toks_cap = 0;
+    // independent GEMMs of a layer (q | k, v and gate | up) run on two streams so that their workgroups share the chip
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
   } pf;
   int prefill_terms = 0;     // MFMAs per product in the prefill GEMMs (0: tl_gemm_set_terms' process-wide value)
   int prefill_min_batch = 8; // prompts shorter than this replay the decode graph token by token
@@ -166,6 +169,9 @@ extern "C" int tl_model_free(tl_model* m) {
   for (float* b : pbufs) hipFree(b);
   hipFree(m->pf.planes);
   hipFree(m->pf.toks);
+  if (m->pf.fork) hipEventDestroy(m->pf.fork);
+  if (m->pf.join) hipEventDestroy(m->pf.join);
+  if (m->pf.side) hipStreamDestroy(m->pf.side);
   if (m->stream) hipStreamDestroy(m->stream);
   delete m;
   return 0;
@@ -795,6 +801,9 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
     TL_HIP(hipMalloc(&p.ub, sizeof(float) * cap * (size_t)m->I_l));
     TL_HIP(hipMalloc(&p.planes, 2 * 3 * p.plane_stride));
     TL_HIP(hipMemsetAsync(p.planes, 0, 2 * 3 * p.plane_stride, m->stream));
+    TL_HIP(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
+    TL_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
+    TL_HIP(hipEventCreateWithFlags(&p.join, hipEventDisableTiming));
     p.cap = cap;
   }
   if (all_logits && !p.logits_all) TL_HIP(hipMalloc(&p.logits_all, sizeof(float) * p.cap * (size_t)c.vocab_size));
@@ -814,9 +823,13 @@ static int enqueue_prefill_chunk(tl_model* m, const int* toks_dev, int T, int st
   for (int l = 0; l < c.num_hidden_layers; ++l) {
     LayerW& L = m->layers[l];
     TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+    TL_HIP(hipEventRecord(p.fork, s));
+    TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
     TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
+    TL_HIP(hipEventRecord(p.join, p.side));
+    TL_HIP(hipStreamWaitEvent(s, p.join, 0));
     TL_TRY(tl_rope_batch(p.qb, p.kb, m->rope, T, m->nh_l, m->nkv_l, hd, start_pos, c.max_position_embeddings, 1, s));
     TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
     TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
@@ -825,8 +838,12 @@ static int enqueue_prefill_chunk(tl_model* m, const int* toks_dev, int T, int st
     TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
     TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s));
     TL_TRY(tl_launch_split(1, p.xb, L.ffn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+    TL_HIP(hipEventRecord(p.fork, s));
+    TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
     TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, p.side));
+    TL_HIP(hipEventRecord(p.join, p.side));
+    TL_HIP(hipStreamWaitEvent(s, p.join, 0));
     TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s));
     TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_DOWN]), p.planes, ps, p.xb, p.xb, T, terms, s));
   }

@@ -102,6 +102,12 @@ int tl_update_kv_cache_batch(float* cache_base_dev, const float* kv_batch_dev, i
 int tl_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev, float* out_dev,
                  int num_heads, int current_seq_len, int head_dim, float scale, int cache_max_seq_len,
                  int cache_num_kv_heads, void* stream);
+/* sample_top_k_top_p_temperature (api.cpp:126-216) as a device operator (the reference only has it on the host):
+ * logits_dev[n] is not modified; u in [0,1) is the caller's uniform variate; *id_dev = the drawn id; optional outputs
+ * (NULL to skip): the candidate ids and renormalised probabilities in draw order (capacity >= min(top_k, n)) and their
+ * count. Effective top_k <= 1024. */
+int tl_sample_top_k_top_p(const float* logits_dev, int n, float temperature, int top_k, float top_p, float u,
+                          int* id_dev, int* cand_ids_dev, float* cand_probs_dev, int* n_cand_dev, void* stream);
 /* attention_batch_prefill_cuda cuda_kernels.h:498 (math of cpu_attention.cpp:91-201), causal from the cache */
 int tl_attention_batch_prefill(const float* q_batch_dev, const float* k_cache_dev, const float* v_cache_dev,
                                float* out_batch_dev, int num_tokens, int start_pos, int cache_max_seq_len,
@@ -151,6 +157,14 @@ int tl_model_decode(tl_model* m, int token_id, int pos, float* logits_host, int*
  * last 64 ids of `history` + what is generated (penalty <= 1: off). */
 int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
                              const int* history_host, int n_history, int* out_ids_host);
+/* The same loop with sample_top_k_top_p_temperature (api.cpp:126-216) on the device instead of arg-max: penalty, FP64
+ * softmax of (logit - max) / temperature rounded to FP32, top_k by (probability, higher id first), FP32 cumulative
+ * top_p cut, renormalisation, inverse-CDF draw as std::discrete_distribution does it. temperature < 0.05 = greedy.
+ * Limit: effective top_k <= 1024 ("no top-k", i.e. top_k <= 0 or >= vocab, is rejected: sample on the host). The
+ * uniform variates come from a counter-based generator keyed by `seed`. */
+int tl_model_generate_sampled(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
+                              const int* history_host, int n_history, float temperature, int top_k, float top_p,
+                              unsigned long long seed, int* out_ids_host);
 /* batched prefill of T prompt tokens starting at start_pos (forward_device_batch_prefill, model.cpp:1526-1862);
  * last_logits_host[vocab] (may be NULL) = logits of the last token; all_logits_host[T][vocab] may be NULL */
 int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,

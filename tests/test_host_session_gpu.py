@@ -47,7 +47,8 @@ def test_session_generate_matches_oracle(H, pkg, oracle, tmp_path, shape, mix):
     a = s.generate(prompt[:6], 12, temperature=1.0, top_k=20, top_p=0.95)
     s.seed(7)
     b = s.generate(prompt[:6], 12, temperature=1.0, top_k=20, top_p=0.95)
-    assert np.array_equal(a, b) and ((a >= 0) & (a < cfg["vocab"])).all() and len(a) == 12
+    assert np.array_equal(a, b) and ((a >= 0) & (a < cfg["vocab"])).all()
+    assert len(a) == 12 or (len(a) < 12 and a[-1] == 2)  # an EOS (id 2 in the synthetic GGUF) ends the stream early
     s.close()
     om.close()
 

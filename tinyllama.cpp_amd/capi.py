@@ -70,6 +70,9 @@ SIGNATURES = {
     "tl_model_generate_greedy": [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp],
     "tl_model_prefill": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
     "tl_model_set_prefill": [_vp, C.c_int, C.c_int],
+    "tl_model_generate_sampled": [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.c_int, C.c_float, C.c_int, C.c_float,
+                                  C.c_uint64, _vp],
+    "tl_sample_top_k_top_p": [_vp, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp],
     "tl_gemm_set_terms": [C.c_int],
     "tl_bench_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), _vp],
     "tl_bench_matvec_prefetch": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float)],

@@ -146,5 +146,20 @@ bool tl_attn_prefill_mfma_supported(int nh, int nkv, int hd);
 int tl_launch_attn_prefill_mfma(const float* q, const float* kc, const float* vc, float* out, int T, int start_pos,
                                 int nh, int nkv, int hd, float scale, hipStream_t s);
 
+// on-device temperature / top-k / top-p sampler (tl_sample.hip)
+constexpr int TL_SAMPLE_MAX_TOP_K = 1024;
+struct TlSampleParams {  // lives in device memory; `counter` is advanced by the kernel
+  float temperature;
+  int top_k;
+  float top_p;
+  int use_fixed_u;
+  float fixed_u;
+  unsigned counter;
+  unsigned long long seed;
+};
+int tl_launch_sample_topk(float* logits, int n, float* probs_scratch, int* state, int state_header, int hist_cap,
+                          TlSampleParams* params_dev, int* out_id, int* cand_ids, float* cand_probs, int* n_cand,
+                          hipStream_t s);
+
 int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, const int* n_hist_dev, float penalty,
                      hipStream_t s);

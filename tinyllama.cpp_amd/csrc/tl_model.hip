@@ -67,6 +67,11 @@ struct tl_model {
   hipStream_t stream = nullptr;
   hipGraph_t graph = nullptr;
   hipGraphExec_t graph_exec = nullptr;
+  // the same step with the top-k / top-p sampler as its tail (captured at the first sampled generation)
+  hipGraph_t graph_sampled = nullptr;
+  hipGraphExec_t graph_exec_sampled = nullptr;
+  TlSampleParams* sparams = nullptr;
+  float* sample_probs = nullptr;
   bool finalized = false;
   bool no_graph = false;  // TL_NO_GRAPH=1: replay steps eagerly (profilers that cannot follow graph launches)
   double weight_bytes = 0.0;  // algorithmic (GGUF) bytes of all per-token matrices incl. one embedding row
@@ -151,6 +156,10 @@ extern "C" int tl_model_free(tl_model* m) {
   if (m->stream) hipStreamSynchronize(m->stream);
   if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
   if (m->graph) hipGraphDestroy(m->graph);
+  if (m->graph_exec_sampled) hipGraphExecDestroy(m->graph_exec_sampled);
+  if (m->graph_sampled) hipGraphDestroy(m->graph_sampled);
+  hipFree(m->sparams);
+  hipFree(m->sample_probs);
   for (auto& l : m->layers) {
     for (auto*& w : l.q) tl_qweight_free(w);
     hipFree(l.attn_norm);
@@ -494,7 +503,12 @@ static int enqueue_sample(tl_model* m, hipStream_t s) {
   return 0;
 }
 
-static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
+static int enqueue_sample_topk(tl_model* m, hipStream_t s) {
+  return tl_launch_sample_topk(m->logits, m->cfg.vocab_size, m->sample_probs, m->state, kStateHeaderInts, m->hist_cap,
+                               m->sparams, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+static int enqueue_step(tl_model* m, StepProf* prof = nullptr, bool sampled = false) {
   hipStream_t s = m->stream;
   PROF_MARK(-1);
   TL_TRY(enqueue_embed(m, s));
@@ -513,7 +527,8 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr) {
     TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
   }
   PROF_MARK(7);
-  TL_TRY(enqueue_sample(m, s));
+  if (sampled) TL_TRY(enqueue_sample_topk(m, s));
+  else TL_TRY(enqueue_sample(m, s));
   PROF_MARK(8);
   return 0;
 }
@@ -765,6 +780,58 @@ extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_
   for (int i = 0; i < n_steps; ++i) {
     if (m->no_graph) TL_TRY(enqueue_step(m));
     else TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+  }
+  if (n_steps > 0 && out_ids_host)
+    TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
+                          hipMemcpyDeviceToHost, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// Sampled generation entirely on the device: the decode step with tl_sample.hip's top-k / top-p sampler as
+// its tail. temperature < 0.05 samples greedily (api.cpp:134). The uniform variates come from a counter-based
+// generator keyed by `seed` (the reference seeds std::mt19937 from std::random_device: not reproducible either).
+extern "C" int tl_model_generate_sampled(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
+                                         const int* history_host, int n_history, float temperature, int top_k,
+                                         float top_p, unsigned long long seed, int* out_ids_host) {
+  TL_REQUIRE(m && m->finalized, "tl_model_generate_sampled: model not finalized");
+  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_generate_sampled: a shard without a communicator cannot step alone");
+  TL_REQUIRE(n_steps >= 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
+             "tl_model_generate_sampled: positions [%d,%d) exceed max_position_embeddings %d", start_pos,
+             start_pos + n_steps, m->cfg.max_position_embeddings);
+  TL_REQUIRE(n_history >= 0 && (n_history == 0 || history_host), "tl_model_generate_sampled: bad history");
+  const int V = m->cfg.vocab_size;
+  const int k = (top_k <= 0 || top_k > V) ? V : top_k;
+  TL_REQUIRE(temperature < 0.05f || k <= TL_SAMPLE_MAX_TOP_K,
+             "tl_model_generate_sampled: effective top_k %d exceeds the device sampler's limit %d (sample on the host)", k,
+             TL_SAMPLE_MAX_TOP_K);
+  const int keep = n_history > 64 ? 64 : n_history;
+  TL_REQUIRE(keep + n_steps <= m->hist_cap, "tl_model_generate_sampled: %d steps exceed the id history capacity", n_steps);
+  if (!m->sparams) {
+    TL_HIP(hipMalloc(&m->sparams, sizeof(TlSampleParams)));
+    TL_HIP(hipMalloc(&m->sample_probs, sizeof(float) * (size_t)V));
+  }
+  TlSampleParams h = {};
+  h.temperature = temperature;
+  h.top_k = top_k;
+  h.top_p = top_p;
+  h.seed = seed;
+  TL_HIP(hipMemcpyAsync(m->sparams, &h, sizeof(h), hipMemcpyHostToDevice, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));  // h lives on this stack frame
+  TL_TRY(set_state(m, first_token, start_pos, penalty, history_host ? history_host + (n_history - keep) : nullptr, keep));
+  if (!m->no_graph && !m->graph_exec_sampled) {  // capture once; a refused capture falls back to eager launches
+    TL_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_step(m, nullptr, true);
+    hipError_t e = hipStreamEndCapture(m->stream, &m->graph_sampled);
+    if (rc == 0 && e == hipSuccess) e = hipGraphInstantiate(&m->graph_exec_sampled, m->graph_sampled, nullptr, nullptr, 0);
+    if (rc != 0 || e != hipSuccess) {
+      (void)hipGetLastError();
+      m->graph_exec_sampled = nullptr;
+    }
+  }
+  for (int i = 0; i < n_steps; ++i) {
+    if (m->graph_exec_sampled) TL_HIP(hipGraphLaunch(m->graph_exec_sampled, m->stream));
+    else TL_TRY(enqueue_step(m, nullptr, true));
   }
   if (n_steps > 0 && out_ids_host)
     TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,

@@ -103,6 +103,21 @@ class QWeight:
             pass
 
 
+def sample_top_k_top_p(logits, temperature, top_k, top_p, u):
+    """Device sampler as an operator: (drawn id, candidate ids, renormalised candidate probabilities)."""
+    l = np.ascontiguousarray(logits, np.float32)
+    cap = l.size if top_k <= 0 or top_k > l.size else top_k
+    lb = DeviceBuffer.from_numpy(l)
+    idb, nb = DeviceBuffer(4), DeviceBuffer(4)
+    cib, cpb = DeviceBuffer(4 * cap), DeviceBuffer(4 * cap)
+    check(lib().tl_sample_top_k_top_p(lb.ptr, l.size, float(temperature), int(top_k), float(top_p), float(u), idb.ptr,
+                                      cib.ptr, cpb.ptr, nb.ptr, None), "tl_sample_top_k_top_p")
+    check(lib().tl_device_sync(), "sync")
+    n = int(nb.to_numpy(np.int32, (1,))[0])
+    return (int(idb.to_numpy(np.int32, (1,))[0]), cib.to_numpy(np.int32, (cap,))[:n].copy(),
+            cpb.to_numpy(np.float32, (cap,))[:n].copy())
+
+
 def tp_unique_id():
     """128 bytes identifying a new RCCL communicator (rank 0 creates it, the host broadcasts it)."""
     buf = (C.c_ubyte * 128)()
@@ -200,6 +215,16 @@ class Model:
         check(lib().tl_model_generate_greedy(self.h, int(first_token), int(start_pos), int(n_steps), float(penalty),
                                              hist.ctypes.data if hist.size else None, hist.size, out.ctypes.data),
               "tl_model_generate_greedy")
+        return out[:n_steps]
+
+    def generate_sampled(self, first_token, start_pos, n_steps, penalty=1.0, history=(), temperature=0.8, top_k=40,
+                         top_p=0.9, seed=0):
+        hist = np.ascontiguousarray(history, np.int32)
+        out = np.zeros(max(n_steps, 1), np.int32)
+        check(lib().tl_model_generate_sampled(self.h, int(first_token), int(start_pos), int(n_steps), float(penalty),
+                                              hist.ctypes.data if hist.size else None, hist.size, float(temperature),
+                                              int(top_k), float(top_p), int(seed), out.ctypes.data),
+              "tl_model_generate_sampled")
         return out[:n_steps]
 
     def set_prefill(self, terms=0, min_batch=8):

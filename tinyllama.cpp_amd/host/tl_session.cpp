@@ -165,6 +165,20 @@ std::vector<int> Session::generate(const std::vector<int>& prompt, int steps, fl
     }
     return generated;
   }
+  const int k_eff = (top_k <= 0 || top_k > V) ? V : top_k;
+  if (k_eff <= 1024) {  // the sampler runs on the device too (tl_sample.hip): no logits cross the bus per token
+    std::vector<int> more((size_t)n_more);
+    const unsigned long long seed = ((unsigned long long)rng_() << 32) | rng_();
+    tl_check(tl_model_generate_sampled(model_, next, P, n_more, repetition_penalty_, generated.data(), 1, temperature,
+                                       top_k, top_p, seed, more.data()),
+             "tl_model_generate_sampled");
+    for (int id : more) {
+      generated.push_back(id);
+      if (id == config_.eos_token_id) break;
+    }
+    return generated;
+  }
+  // "no top-k" over a large vocabulary: logits back per token, the reference's host sampler
   for (pos = P; pos < P + n_more; ++pos) {
     tl_check(tl_model_decode(model_, next, pos, logits.data(), nullptr), "tl_model_decode");
     apply_repetition_penalty(logits, generated, repetition_penalty_);

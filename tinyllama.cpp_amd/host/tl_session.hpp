@@ -40,7 +40,8 @@ class Session {
   Session& operator=(const Session&) = delete;
 
   // TinyLlamaSession::generate on ids: returns the generated ids (prompt excluded). temperature < 0.05 is greedy
-  // (api.cpp:134) and runs entirely on the device; otherwise top-k / top-p sampling on the logits (api.cpp:126-216).
+  // (api.cpp:134) and runs entirely on the device; otherwise top-k / top-p sampling (api.cpp:126-216), on the device as
+  // well when the effective top_k is <= 1024 (tl_model_generate_sampled), else on the host from the returned logits.
   std::vector<int> generate(const std::vector<int>& prompt_ids, int steps = 128, float temperature = 0.1f, int top_k = 40,
                             float top_p = 0.9f);
 

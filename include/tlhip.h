@@ -63,6 +63,9 @@ int tl_qweight_info(const tl_qweight* w, int* type, int* rows, int* cols, size_t
  * dequantize_q8_0_block / dequantize_q8_k, quantization.cpp:171-266, 1009-1052): rows [row0, row0+nrows)
  * -> out_dev[nrows*cols] f32. Also what lookup_embedding (model_utils.cpp:11-182) becomes for one row. */
 int tl_dequantize_rows(const tl_qweight* w, int row0, int nrows, float* out_dev, void* stream);
+/* quantize_fp32_to_q8_K (quantization.cpp:719-770) on the device, bit-exact: n (multiple of 256) FP32 values ->
+ * n/256 GGUF Q8_K blocks of 290 B {d:f16, qs[256]:i8, bsums[16]:i16} at blocks_dev */
+int tl_quantize_q8_k(const float* x_dev, size_t n, void* blocks_dev, void* stream);
 
 /* y[rows] = W x : replaces matvec_f32_f32_cuda (cuda_kernels.h:171) / matvec_bf16_f32_cuda (:424), on the
  * quantized weights directly. FP32 accumulate; tolerance vs the reference's Kahan-double CPU dot is stated

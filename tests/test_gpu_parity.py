@@ -336,3 +336,25 @@ def test_model_errors(E, pkg):
     with pytest.raises(TlError):
         m.decode(0, cfg["max_pos"])  # position beyond the cache
     m.free()
+
+
+def test_quantize_q8_k_bit_exact(E, oracle):
+    """quantize_fp32_to_q8_K on the device == the oracle byte for byte (scales through the reference's own float->half
+    rule, round-half-away quantization, bsums), incl. all-zero blocks, huge / tiny magnitudes and exact .5 ties."""
+    from tinyllama_cpp_amd.capi import lib, check
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal(256 * 40) * 3).astype(np.float32)
+    x[:256] = 0.0
+    x[256:512] *= 1e-7   # scale in the fp16 subnormal range
+    x[512:768] *= 1e4
+    x[768:1024] = np.round(x[768:1024] * 4) / 8  # many products that land on .5 after scaling
+    x[1024:1280] *= 1e6  # d overflows fp16 -> inf
+    xb = E.DeviceBuffer.from_numpy(x)
+    ob = E.DeviceBuffer(x.size // 256 * 290)
+    check(lib().tl_quantize_q8_k(xb.ptr, x.size, ob.ptr, None))
+    check(lib().tl_device_sync())
+    got = ob.to_numpy(np.uint8, (x.size // 256 * 290,))
+    assert np.array_equal(got, oracle.quantize_q8_k(x))
+    from tinyllama_cpp_amd.capi import TlError
+    with pytest.raises(TlError):
+        check(lib().tl_quantize_q8_k(xb.ptr, 100, ob.ptr, None))

@@ -69,6 +69,7 @@ SIGNATURES = {
     "tl_model_decode": [_vp, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
     "tl_model_generate_greedy": [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.c_int, _vp],
     "tl_model_prefill": [_vp, _vp, C.c_int, C.c_int, _vp, _vp],
+    "tl_quantize_q8_k": [_vp, _sz, _vp, _vp],
     "tl_model_set_prefill": [_vp, C.c_int, C.c_int],
     "tl_model_generate_sampled": [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, C.c_int, C.c_float, C.c_int, C.c_float,
                                   C.c_uint64, _vp],

@@ -371,3 +371,76 @@ extern "C" int tl_lookup_embedding(const tl_qweight* table, int token_id, float*
   }
   return tl_launch_dequant_rows(table, nullptr, token_id, 1, out_dev, s);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// FP32 -> Q8_K blocks on the device (quantize_fp32_to_q8_K, quantization.cpp:719-770), bit-exact: per 256 values
+// d = max|x| / 127 stored through the reference's own float->half rule (quantization.cpp:92-143: the mantissa is bumped
+// by one half-ulp step whenever bit 13 is set, which is not IEEE round-to-nearest-even), q = clamp(roundf(x * (1/d))),
+// bsums = the sixteen 16-element sums of q. One wave per block, output in the GGUF block layout (290 B).
+// ---------------------------------------------------------------------------------------------------
+__device__ inline uint32_t float_to_half_bits_ref(float f) {
+  const uint32_t x = __float_as_uint(f);
+  const uint32_t sign = (x >> 31) & 1u, e32 = (x >> 23) & 0xffu;
+  uint32_t m = x & 0x7fffffu;
+  if (e32 == 0xff) return (sign << 15) | 0x7c00u | (m != 0 ? 0x200u : 0u);
+  int e16 = (int)e32 - 112;
+  if (e16 >= 0x1f) return (sign << 15) | 0x7c00u;
+  if (e16 <= 0) {
+    if (e16 < -10) return sign << 15;
+    m = (m | 0x800000u) >> (1 - e16);
+    if ((m >> 13) & 1u) m += 1u << 13;
+    return (sign << 15) | (m >> 13);
+  }
+  if ((m >> 13) & 1u) {
+    m += 1u << 13;
+    if ((m >> 23) == 1u) {
+      m = 0;
+      if (++e16 >= 0x1f) return (sign << 15) | 0x7c00u;
+    }
+  }
+  return (sign << 15) | ((uint32_t)e16 << 10) | (m >> 13);
+}
+
+__global__ __launch_bounds__(64) void quantize_q8k_kernel(const float* __restrict__ x, uint8_t* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x;
+  const float* xb = x + (size_t)blockIdx.x * 256;
+  uint8_t* ob = out + (size_t)blockIdx.x * 290;
+  const float4 v = reinterpret_cast<const float4*>(xb)[lane];  // values 4*lane .. 4*lane+3
+  float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+  for (int o = 32; o >= 1; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+  const float d = __fdiv_rn(amax, 127.0f);
+  const float id = d != 0.f ? __fdiv_rn(1.0f, d) : 0.0f;
+  const float xs[4] = {v.x, v.y, v.z, v.w};
+  int q[4], sum = 0;
+  for (int i = 0; i < 4; ++i) {
+    float r = roundf(__fmul_rn(xs[i], id));
+    r = fminf(127.0f, r);
+    r = fmaxf(-128.0f, r);
+    q[i] = (int)r;
+    sum += q[i];
+  }
+  // 16-element sums: 4 lanes each
+  sum += __shfl_xor(sum, 1);
+  sum += __shfl_xor(sum, 2);
+  if (lane == 0) {
+    const uint32_t h = float_to_half_bits_ref(d);
+    ob[0] = (uint8_t)(h & 0xff);
+    ob[1] = (uint8_t)(h >> 8);
+  }
+  for (int i = 0; i < 4; ++i) ob[2 + 4 * lane + i] = (uint8_t)(int8_t)q[i];
+  if ((lane & 3) == 0) {
+    const int16_t s16 = (int16_t)sum;
+    ob[258 + 2 * (lane >> 2)] = (uint8_t)((uint16_t)s16 & 0xff);
+    ob[259 + 2 * (lane >> 2)] = (uint8_t)((uint16_t)s16 >> 8);
+  }
+}
+
+extern "C" int tl_quantize_q8_k(const float* x_dev, size_t n, void* blocks_dev, void* stream) {
+  TL_REQUIRE(x_dev && blocks_dev, "tl_quantize_q8_k: null argument");
+  TL_REQUIRE(n % 256 == 0, "tl_quantize_q8_k: %zu values are not a multiple of the 256-element block", n);
+  if (n == 0) return 0;
+  quantize_q8k_kernel<<<(unsigned)(n / 256), 64, 0, static_cast<hipStream_t>(stream)>>>(x_dev, static_cast<uint8_t*>(blocks_dev));
+  TL_HIP(hipGetLastError());
+  return 0;
+}

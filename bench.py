@@ -202,8 +202,12 @@ def main():
     }
 
     # ---- batched prefill on the matrix cores (outside the timed decode region): 512 prompt tokens, FP32-grade 6-term form
-    if world == 1 and cfg["max_pos"] >= 512 + 8 and not args.no_prefill_leg:
-        out["prefill"] = prefill_leg(model, S, cfg, mix, 512)
+    # (under tensor parallelism every rank runs it: the prefill's all-reduces are collective calls)
+    if cfg["max_pos"] >= 512 + 8 and not args.no_prefill_leg:
+        try:
+            out["prefill"] = prefill_leg(model, S, cfg, mix, 512, world=world)
+        except Exception as e:  # the decode numbers above stay valid
+            out["prefill"] = {"error": str(e)[:300]}
 
     # ---- CPU baseline: the oracle in the reference's structure on a bounded sample ------------------------------
     if want_cpu:
@@ -214,7 +218,7 @@ def main():
         dist.destroy_process_group()
 
 
-def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3):
+def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3, world=1):
     """tokens/s of tl_model_prefill (MFMA GEMMs over the quantized weights, FP32-MFMA attention) for a T-token prompt;
     executed bf16 MFMA flops = terms x the algorithmic GEMM flops 2*T*(layer weight elements)."""
     toks = np.random.default_rng(1).integers(0, cfg["vocab"], T).astype(np.int32)
@@ -228,12 +232,13 @@ def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3):
         model.prefill(toks, 0)
         best = min(best, time.perf_counter() - t0)
     elems = sum(r * c for n, t, r, c in S.tensor_plan(cfg, mix) if n.startswith("blk.") and t != S.F32)
-    flops = 2.0 * T * elems
+    flops = 2.0 * T * elems / world  # per GPU
     return {"prompt_tokens": T, "mfma_terms": terms, "ms": round(best * 1e3, 2), "tokens_per_s": round(T / best, 1),
             "gemm_tflops_algorithmic": round(flops / best / 1e12, 1),
             "bf16_mfma_tflops_executed": round(flops * terms / best / 1e12, 1),
             "frac_of_bf16_dense_peak": round(flops * terms / best / 2.5e15, 4),
-            "note": "whole prefill wall time incl. attention and glue; per-kernel MFMA busy counters: profiles/"}
+            "note": "whole prefill wall time incl. attention and glue (rank 0's clock; TFLOP/s per GPU); per-kernel MFMA "
+                    "busy counters: profiles/"}
 
 
 def cpu_baseline(cfg, keep, n_layers, w_bytes):

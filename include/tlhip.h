@@ -222,6 +222,10 @@ int tl_model_graph_captured(const tl_model* m, int* captured_out);
 int tl_tp_local_group_decode(tl_model* const* shards, int n, int token_id, int pos, float* logits_host,
                              int* next_token_host);
 
+/* the same for the batched prefill of a prompt (collectives as plain kernels); last_logits_host[vocab] may be NULL */
+int tl_tp_local_group_prefill(tl_model* const* shards, int n, const int* tokens_host, int num_tokens, int start_pos,
+                              float* last_logits_host);
+
 #ifdef __cplusplus
 }
 #endif

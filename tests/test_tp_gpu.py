@@ -75,3 +75,36 @@ def test_rccl_calls_capture_on_one_rank(pkg, monkeypatch):
     assert m.graph_captured(), "RCCL collectives were not captured into the decode graph (eager fallback)"
     m.free()
     plain.free()
+
+
+@pytest.mark.parametrize("shape,mix,tp,T", [("tiny-gqa", "q4_k_m", 2, 70), ("tiny-tp", "q4_k_m", 4, 33), ("tiny-tp", "q6_k", 2, 100)])
+def test_tp_local_group_prefill_matches_oracle(pkg, oracle, shape, mix, tp, T):
+    """Batched (MFMA) prefill of a sharded model: per-rank GEMMs on the shards, one T x hidden all-reduce per projection
+    pair, vocabulary-sharded last-token logits; then sharded decode continues from the sharded caches."""
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model(shape, mix, seed=9)
+    shards = [E.Model(cfg, tp_rank=r, tp_size=tp).load(tensors) for r in range(tp)]
+    om = OracleModel(oracle, cfg, tensors)
+    toks = np.random.default_rng(T).integers(0, cfg["vocab"], T).astype(np.int32)
+    X = np.stack([om.lookup_embedding(t) for t in toks])
+    _, lb = om.forward_batch(X, 0)
+    last = E.tp_local_group_prefill(shards, toks, 0)
+    assert close(last, lb[-1], LOGIT_TOL).all(), np.abs(last - lb[-1]).max()
+    hd = cfg["hidden"] // cfg["n_heads"]
+    kvl = cfg["n_kv_heads"] // tp * hd
+    from tinyllama_cpp_amd.capi import check, lib
+    for r, m in enumerate(shards):
+        kvd = np.empty((T, kvl), np.float32)
+        check(lib().tl_memcpy_d2h(kvd.ctypes.data, m.device_ptr(0, cfg["n_layers"] - 1), kvd.nbytes, None), "d2h")
+        assert close(kvd, om.kcache(cfg["n_layers"] - 1, T)[:, r * kvl:(r + 1) * kvl], LOGIT_TOL).all()
+    tok = int(np.argmax(lb[-1]))
+    for i in range(4):  # decode goes on from the prefilled, sharded caches
+        _, want = om.forward(om.lookup_embedding(tok), T + i)
+        logits, nxt = E.tp_local_group_decode(shards, tok, T + i)
+        assert close(logits, want, LOGIT_TOL).all()
+        assert nxt == int(np.argmax(want))
+        tok = nxt
+    for m in shards:
+        m.free()
+    om.close()

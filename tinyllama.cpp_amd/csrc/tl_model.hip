@@ -79,6 +79,7 @@ struct tl_model {
   struct Prefill {
     int cap = 0;               // tokens per chunk the buffers hold
     float *xb = nullptr, *qb = nullptr, *kb = nullptr, *vb = nullptr, *ab = nullptr, *gb = nullptr, *ub = nullptr;
+    float* xpart = nullptr;    // tp > 1: this rank's partial of attn_output / ffn_down for the chunk, all-reduced into xb
     void* planes = nullptr;    // bf16 [3][plane_stride]
     size_t plane_stride = 0;
     float* logits_all = nullptr;  // [cap][vocab], only when all logits were asked for
@@ -174,7 +175,7 @@ extern "C" int tl_model_free(tl_model* m) {
   hipFree(m->cand_v);
   hipFree(m->cand_i);
   hipFree(m->attn_ws);
-  float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all};
+  float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all, m->pf.xpart};
   for (float* b : pbufs) hipFree(b);
   hipFree(m->pf.planes);
   hipFree(m->pf.toks);
@@ -845,8 +846,7 @@ extern "C" int tl_model_generate_sampled(tl_model* m, int first_token, int start
 // A chunk of up to kPrefillChunk tokens goes through every layer as a batch: RMSNorm -> bf16 planes, q/k/v GEMMs on
 // the matrix cores (tl_gemm.hip), batched RoPE + KV write, causal attention from the cache (tl_prefill.hip), O GEMM +
 // residual, RMSNorm -> planes, gate/up GEMMs, SwiGLU -> planes, down GEMM + residual. Longer prompts are walked chunk by
-// chunk over the growing cache. Short prompts (< prefill_min_batch) and tensor-parallel shards replay the decode graph
-// token by token instead (same positions, KV contents and logits to ~1e-6).
+// chunk over the growing cache. Short prompts (< prefill_min_batch) replay the decode graph token by token instead (same positions, KV contents and logits to ~1e-6).
 constexpr int kPrefillChunk = 512;
 
 __global__ void set_token_kernel(int* state, const int* tokens, int i) { state[0] = tokens[i]; }
@@ -860,6 +860,7 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
     const size_t kmax = maxk > (size_t)m->qd_l ? maxk : (size_t)m->qd_l;
     p.plane_stride = tl_gemm_padded_tokens(cap) * kmax;
     TL_HIP(hipMalloc(&p.xb, sizeof(float) * cap * H));
+    if (m->tp > 1) TL_HIP(hipMalloc(&p.xpart, sizeof(float) * cap * H));
     TL_HIP(hipMalloc(&p.qb, sizeof(float) * cap * (size_t)m->qd_l));
     TL_HIP(hipMalloc(&p.kb, sizeof(float) * cap * (size_t)m->kv_dim));
     TL_HIP(hipMalloc(&p.vb, sizeof(float) * cap * (size_t)m->kv_dim));
@@ -877,52 +878,71 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
   return 0;
 }
 
-// one chunk: tokens toks_dev[0..T) at positions start_pos.., T <= pf.cap; leaves the residual stream in pf.xb
-static int enqueue_prefill_chunk(tl_model* m, const int* toks_dev, int T, int start_pos) {
+// One chunk (tokens toks_dev[0..T) at positions start_pos.., T <= pf.cap) in pieces, so that a tensor-parallel group can
+// be driven in lockstep; the residual stream lives in pf.xb. tp > 1: the row-split GEMMs (attn_output, ffn_down) write
+// this rank's partial for the whole chunk into pf.xpart (rank 0 folds the residual in) and ONE all-reduce of T x hidden
+// floats per projection pair turns the partials into the new residual stream.
+static int prefill_embed(tl_model* m, const int* toks_dev, int T, hipStream_t s) {
+  return tl_launch_dequant_gather(m->tok, toks_dev, T, m->pf.xb, s);
+}
+static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream_t s) {
   const tl_model_config& c = m->cfg;
   tl_model::Prefill& p = m->pf;
-  hipStream_t s = m->stream;
+  LayerW& L = m->layers[l];
   const int H = c.hidden_size, hd = m->head_dim;
   const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
   const size_t ps = p.plane_stride;
   const float scale = 1.0f / sqrtf((float)hd);
-  TL_TRY(tl_launch_dequant_gather(m->tok, toks_dev, T, p.xb, s));
-  for (int l = 0; l < c.num_hidden_layers; ++l) {
-    LayerW& L = m->layers[l];
-    TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
-    TL_HIP(hipEventRecord(p.fork, s));
-    TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
-    TL_HIP(hipEventRecord(p.join, p.side));
-    TL_HIP(hipStreamWaitEvent(s, p.join, 0));
-    TL_TRY(tl_rope_batch(p.qb, p.kb, m->rope, T, m->nh_l, m->nkv_l, hd, start_pos, c.max_position_embeddings, 1, s));
-    TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
-    TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
-    TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
-                                      m->nkv_l, hd, scale, s));
-    TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s));
-    TL_TRY(tl_launch_split(1, p.xb, L.ffn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
-    TL_HIP(hipEventRecord(p.fork, s));
-    TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, p.side));
-    TL_HIP(hipEventRecord(p.join, p.side));
-    TL_HIP(hipStreamWaitEvent(s, p.join, 0));
-    TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_DOWN]), p.planes, ps, p.xb, p.xb, T, terms, s));
-  }
-  return 0;
+  TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+  TL_HIP(hipEventRecord(p.fork, s));
+  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
+  TL_HIP(hipEventRecord(p.join, p.side));
+  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  TL_TRY(tl_rope_batch(p.qb, p.kb, m->rope, T, m->nh_l, m->nkv_l, hd, start_pos, c.max_position_embeddings, 1, s));
+  TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+  TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+  TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
+                                    m->nkv_l, hd, scale, s));
+  TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+  return tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, m->tp > 1 ? p.xpart : p.xb,
+                          m->rank == 0 ? p.xb : nullptr, T, terms, s);
 }
-
-static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
-                           float* all_logits_host) {
+static int prefill_mlp_half(tl_model* m, int l, int T, hipStream_t s) {
   const tl_model_config& c = m->cfg;
   tl_model::Prefill& p = m->pf;
-  hipStream_t s = m->stream;
-  TL_TRY(ensure_prefill_ws(m, all_logits_host != nullptr));
+  LayerW& L = m->layers[l];
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  const size_t ps = p.plane_stride;
+  TL_TRY(tl_launch_split(1, p.xb, L.ffn_norm, p.planes, ps, T, c.hidden_size, terms, c.rms_norm_eps, s));
+  TL_HIP(hipEventRecord(p.fork, s));
+  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, p.side));
+  TL_HIP(hipEventRecord(p.join, p.side));
+  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s));
+  return tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_DOWN]), p.planes, ps, m->tp > 1 ? p.xpart : p.xb,
+                          m->rank == 0 ? p.xb : nullptr, T, terms, s);
+}
+static int prefill_all_reduce(tl_model* m, int T, hipStream_t s) {
+  if (m->tp == 1) return 0;
+  TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
+  TL_NCCL(ncclAllReduce(m->pf.xpart, m->pf.xb, (size_t)T * m->cfg.hidden_size, ncclFloat, ncclSum, m->comm, s));
+  return 0;
+}
+// logits of the chunk's last token through the decode step's fused norm + lm_head GEMV (this rank's vocabulary rows)
+static int prefill_head(tl_model* m, int T, hipStream_t s) {
+  const size_t H = m->cfg.hidden_size;
+  TL_HIP(hipMemcpyAsync(m->x, m->pf.xb + (size_t)(T - 1) * H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+  return enqueue_head(m, s);
+}
+
+static int prepare_prefill(tl_model* m, const int* tokens_host, int num_tokens, bool all_logits, hipStream_t s) {
+  tl_model::Prefill& p = m->pf;
+  TL_TRY(ensure_prefill_ws(m, all_logits));
   if (p.toks_cap < num_tokens) {
     if (p.toks) TL_HIP(hipFree(p.toks));
     p.toks = nullptr;
@@ -931,25 +951,112 @@ static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, 
     p.toks_cap = num_tokens;
   }
   TL_HIP(hipMemcpyAsync(p.toks, tokens_host, sizeof(int) * (size_t)num_tokens, hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
+                           float* all_logits_host) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  hipStream_t s = m->stream;
+  TL_TRY(prepare_prefill(m, tokens_host, num_tokens, all_logits_host != nullptr, s));
   const size_t H = c.hidden_size, V = c.vocab_size;
   const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
   for (int c0 = 0; c0 < num_tokens; c0 += p.cap) {
     const int T = num_tokens - c0 < p.cap ? num_tokens - c0 : p.cap;
-    TL_TRY(enqueue_prefill_chunk(m, p.toks + c0, T, start_pos + c0));
+    TL_TRY(prefill_embed(m, p.toks + c0, T, s));
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+      TL_TRY(prefill_attn_half(m, l, T, start_pos + c0, s));
+      TL_TRY(prefill_all_reduce(m, T, s));
+      TL_TRY(prefill_mlp_half(m, l, T, s));
+      TL_TRY(prefill_all_reduce(m, T, s));
+    }
     if (all_logits_host) {  // final norm + lm_head for every token of the chunk (forward_cpu_logits_batch, model.cpp:1094-1156)
       TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, (int)H, terms, c.rms_norm_eps, s));
       TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
       TL_HIP(hipMemcpyAsync(all_logits_host + (size_t)c0 * V, p.logits_all, sizeof(float) * (size_t)T * V,
                             hipMemcpyDeviceToHost, s));
     }
-    if (c0 + T == num_tokens) {  // logits of the last token through the decode step's fused norm + lm_head GEMV
-      TL_HIP(hipMemcpyAsync(m->x, p.xb + (size_t)(T - 1) * H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
-      TL_TRY(enqueue_head(m, s));
+    if (c0 + T == num_tokens) {
+      TL_TRY(prefill_head(m, T, s));
+      if (m->tp > 1)
+        TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
       if (last_logits_host)
         TL_HIP(hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, s));
     }
   }
   TL_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// The batched prefill of a whole tensor-parallel group inside ONE process on ONE device (test hook, as above).
+__global__ void group_sum_rows_kernel(const float* const* __restrict__ parts, float* const* __restrict__ outs, int n,
+                                      size_t len) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= len) return;
+  float acc = 0.f;
+  for (int r = 0; r < n; ++r) acc += parts[r][i];
+  for (int r = 0; r < n; ++r) outs[r][i] = acc;
+}
+
+extern "C" int tl_tp_local_group_prefill(tl_model* const* ms, int n, const int* tokens_host, int num_tokens,
+                                         int start_pos, float* last_logits_host) {
+  TL_REQUIRE(ms && n >= 2 && n <= 16 && tokens_host && num_tokens > 0, "tl_tp_local_group_prefill: bad argument");
+  tl_model* m0 = ms[0];
+  for (int r = 0; r < n; ++r)
+    TL_REQUIRE(ms[r] && ms[r]->allocated && ms[r]->tp == n && ms[r]->rank == r,
+               "tl_tp_local_group_prefill: member %d is not rank %d of a finalized %d-way group", r, r, n);
+  TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m0->cfg.max_position_embeddings,
+             "tl_tp_local_group_prefill: positions out of range");
+  hipStream_t s = m0->stream;
+  for (int r = 0; r < n; ++r) TL_TRY(prepare_prefill(ms[r], tokens_host, num_tokens, false, s));
+  std::vector<const float*> parts(n);
+  std::vector<float*> outs(n);
+  for (int r = 0; r < n; ++r) {
+    parts[r] = ms[r]->pf.xpart;
+    outs[r] = ms[r]->pf.xb;
+  }
+  const float** parts_dev = nullptr;
+  float** outs_dev = nullptr;
+  TL_HIP(hipMalloc(&parts_dev, sizeof(float*) * n));
+  TL_HIP(hipMalloc(&outs_dev, sizeof(float*) * n));
+  TL_HIP(hipMemcpy(parts_dev, parts.data(), sizeof(float*) * n, hipMemcpyHostToDevice));
+  TL_HIP(hipMemcpy(outs_dev, outs.data(), sizeof(float*) * n, hipMemcpyHostToDevice));
+  int rc = 0;
+  auto all = [&](auto&& f) {
+    for (int r = 0; r < n && rc == 0; ++r) rc = f(ms[r]);
+  };
+  const int cap = m0->pf.cap, H = m0->cfg.hidden_size, V = m0->cfg.vocab_size;
+  for (int c0 = 0; c0 < num_tokens && rc == 0; c0 += cap) {
+    const int T = num_tokens - c0 < cap ? num_tokens - c0 : cap;
+    const size_t len = (size_t)T * H;
+    auto reduce = [&]() {
+      if (rc == 0) group_sum_rows_kernel<<<(unsigned)((len + 255) / 256), 256, 0, s>>>(parts_dev, outs_dev, n, len);
+    };
+    all([&](tl_model* m) { return prefill_embed(m, m->pf.toks + c0, T, s); });
+    for (int l = 0; l < m0->cfg.num_hidden_layers && rc == 0; ++l) {
+      all([&](tl_model* m) { return prefill_attn_half(m, l, T, start_pos + c0, s); });
+      reduce();
+      all([&](tl_model* m) { return prefill_mlp_half(m, l, T, s); });
+      reduce();
+    }
+    if (c0 + T == num_tokens) {
+      all([&](tl_model* m) { return prefill_head(m, T, s); });
+      for (int r = 1; r < n && rc == 0; ++r)  // rank r's vocabulary rows into rank 0's logits
+        if (hipMemcpyAsync(m0->logits + (size_t)r * ms[r]->V_l, ms[r]->logits + (size_t)r * ms[r]->V_l,
+                           sizeof(float) * (size_t)ms[r]->V_l, hipMemcpyDeviceToDevice, s) != hipSuccess)
+          rc = 1;
+      if (rc == 0 && last_logits_host &&
+          hipMemcpyAsync(last_logits_host, m0->logits, sizeof(float) * (size_t)V, hipMemcpyDeviceToHost, s) != hipSuccess)
+        rc = 1;
+    }
+  }
+  const hipError_t e = hipStreamSynchronize(s);
+  hipFree(parts_dev);
+  hipFree(outs_dev);
+  if (rc > 1) return rc;
+  TL_REQUIRE(rc == 0, "tl_tp_local_group_prefill: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+  TL_HIP(e);
   return 0;
 }
 
@@ -970,7 +1077,8 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m->cfg.max_position_embeddings,
              "tl_model_prefill: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + num_tokens,
              m->cfg.max_position_embeddings);
-  if (m->tp == 1 && num_tokens >= m->prefill_min_batch)
+  // (all-token logits of a vocabulary-sharded lm_head are not gathered: that request takes the token-by-token route)
+  if (num_tokens >= m->prefill_min_batch && (m->tp == 1 || !all_logits_host))
     return prefill_batched(m, tokens_host, num_tokens, start_pos, last_logits_host, all_logits_host);
   int* toks_dev = nullptr;
   TL_HIP(hipMalloc(&toks_dev, sizeof(int) * (size_t)num_tokens));

@@ -136,6 +136,17 @@ def tp_local_group_decode(models, token, pos, want_logits=True):
     return logits, nxt.value
 
 
+def tp_local_group_prefill(models, tokens, start_pos=0):
+    """Batched prefill of a tensor-parallel group whose shards all live in this process (test hook): last logits."""
+    n = len(models)
+    arr = (C.c_void_p * n)(*[m.h for m in models])
+    toks = np.ascontiguousarray(tokens, np.int32)
+    last = np.empty(models[0].cfg["vocab"], np.float32)
+    check(lib().tl_tp_local_group_prefill(arr, n, toks.ctypes.data, toks.size, int(start_pos), last.ctypes.data),
+          "tl_tp_local_group_prefill")
+    return last
+
+
 KINDS = {"attn_q": capi.T_ATTN_Q, "attn_k": capi.T_ATTN_K, "attn_v": capi.T_ATTN_V,
          "attn_output": capi.T_ATTN_OUTPUT, "ffn_gate": capi.T_FFN_GATE, "ffn_up": capi.T_FFN_UP,
          "ffn_down": capi.T_FFN_DOWN, "attn_norm": capi.T_ATTN_NORM, "ffn_norm": capi.T_FFN_NORM}

@@ -18,9 +18,11 @@
 //     at 1/6 of the bf16 rate the 6-term form is still ~2.7x the chip's FP32 MFMA/VALU rate;
 //   - the activation planes are produced ONCE per GEMM input by the producer kernel (RMSNorm, SwiGLU or a plain
 //     split, below), not by every workgroup that consumes them;
-//   - tile: 128 tokens x 64 or 128 weight rows x 32 columns per step, 4 waves (each 64 tokens x 32 or 64 rows = two
-//     or four 32x32 accumulators); XOR-swizzled 64-B LDS rows (fragment reads and staging writes bank-conflict free),
-//     two LDS buffers and one barrier per step, global loads two steps ahead in registers;
+//   - tile: 128 tokens x 64 weight rows x 32 columns per step; XOR-swizzled 64-B LDS rows (fragment reads and staging
+//     writes bank-conflict free), two LDS buffers and one barrier per step. Default kernel: wave-specialised, 8 waves =
+//     4 producers (global loads three steps ahead in registers, dequantize + split, LDS writes) + 4 consumers (fragment
+//     reads + MFMAs, 64 tokens x 32 rows each), gemm_q_ws_kernel; the unified 4-wave kernel (gemm_q_kernel, also with
+//     128-row tiles) is kept for A/B runs (TL_GEMM_WS=0): it measured 13 % slower end to end;
 //   - workgroup -> tile mapping is XCD-aware: the 8 XCDs (round-robin over blockIdx) each walk a contiguous range of
 //     weight-row tiles of ONE token panel, so a panel's activation planes (<= 3 MB) stay in that XCD's L2.
 #include <stdlib.h>
@@ -258,6 +260,140 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16
   }
 }
 
+// ---- the wave-specialised form: 8 waves, 4 producers + 4 consumers ---------------------------------------------------------
+// In the kernel above a wave alternates between staging (global loads, dequantize + split on the VALU, LDS writes) and
+// MFMAs, and the two only overlap across co-resident workgroups. Here the roles are split: waves 4-7 do nothing but
+// staging, with loads two steps ahead in registers (they hold no accumulators), waves 0-3 nothing but fragment reads and
+// MFMAs; every SIMD hosts one wave of each kind, so its VALU and its matrix pipe run side by side. Same tile (64 weight
+// rows x 128 tokens x 32 columns per step), same two swizzled LDS buffers, one workgroup barrier per step.
+constexpr int WS_THREADS = 512;
+
+template <int TYPE, int NP, int NT>
+__global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
+                                                               float* __restrict__ y, const float* __restrict__ resid,
+                                                               int T, int mtiles, int ntiles) {
+  constexpr int BM = 64;
+  constexpr int WPL = BM * LROW, XPL = GB_N * LROW;
+  constexpr int BUF = NP * (WPL + XPL);
+  extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
+  const int M = w.rows, K = w.cols;
+  const int total = mtiles * ntiles;
+  int tile = blockIdx.x;
+  if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int nt = tile / mtiles, mt = tile - nt * mtiles;
+  const int m0 = mt * BM, n0 = nt * GB_N;
+  const int nk = K / GB_K, last = nk - 1;
+  const int nk3 = (nk + 2) / 3 * 3;  // both roles run a multiple of three steps (the tail steps only meet at the barrier)
+  if (threadIdx.x >= 256) {
+    // ---------------- producers (waves 4-7: with round-robin wave placement one per SIMD, next to one consumer) ----------
+    const int tid = threadIdx.x - 256;
+    const int wrow = tid >> 2, wq = tid & 3;
+    const int grow = m0 + wrow < M ? m0 + wrow : M - 1;
+    const int xr0 = tid >> 2, xr1 = xr0 + 64, xs = tid & 3;
+    const __bf16* xg0 = xp + (size_t)(n0 + xr0) * K + xs * 8;
+    const __bf16* xg1 = xp + (size_t)(n0 + xr1) * K + xs * 8;
+    struct Regs {
+      Raw8 rw;
+      bf16x8 rx[NP][2];
+    };
+    // three register sets in rotation, the loop unrolled by three so that the rotation is register renaming and not
+    // copying (a copy of a set with loads in flight would wait for them): at step kk the set (kk+1)%3 holds step kk+1
+    // (staged now), (kk+2)%3 holds step kk+2, and the set that held step kk is refilled with step kk+3.
+    Regs s0, s1, s2;
+    auto fetch = [&](Regs& g, int kn) {
+      kn = kn < last ? kn : last;  // clamped, unconditional: the waits stay counted
+      g.rw = load8<TYPE>(w, grow, kn, wq);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        g.rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride + (size_t)kn * GB_K);
+        g.rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride + (size_t)kn * GB_K);
+      }
+    };
+    auto stage = [&](const Regs& g, int buf, int kn) {
+      kn = kn < last ? kn : last;
+      __bf16* wb = lds + buf * BUF;
+      __bf16* xb = wb + NP * WPL;
+      float wv[8];
+      deq8<TYPE>(g.rw, kn, wq, wv);
+      bf16x8 wp[NP];
+      split8<NP>(wv, wp);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        *reinterpret_cast<bf16x8*>(wb + p * WPL + lds_off(wrow, wq)) = wp[p];
+        *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0, xs)) = g.rx[p][0];
+        *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr1, xs)) = g.rx[p][1];
+      }
+    };
+    fetch(s0, 0);
+    fetch(s1, 1);
+    fetch(s2, 2);
+    stage(s0, 0, 0);
+    __syncthreads();  // buffer 0 holds step 0
+    for (int kk = 0; kk < nk3; kk += 3) {
+      fetch(s0, kk + 3);
+      stage(s1, (kk + 1) & 1, kk + 1);
+      __syncthreads();
+      fetch(s1, kk + 4);
+      stage(s2, (kk + 2) & 1, kk + 2);
+      __syncthreads();
+      fetch(s2, kk + 5);
+      stage(s0, (kk + 3) & 1, kk + 3);
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------- consumers ----------------
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  __syncthreads();
+  for (int kk = 0; kk < nk3; ++kk) {
+    if (kk >= nk) {  // uniform
+      __syncthreads();
+      continue;
+    }
+    const __bf16* wb = lds + (kk & 1) * BUF;
+    const __bf16* xb = wb + NP * WPL;
+    bf16x8 a[2][NP][2], b[2][NP];
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        a[k16][p][0] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + fr, k16 * 2 + fh));
+        a[k16][p][1] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 + fr, k16 * 2 + fh));
+        b[k16][p] = *reinterpret_cast<const bf16x8*>(wb + p * WPL + lds_off(wm * 32 + fr, k16 * 2 + fh));
+      }
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int k16 = 0; k16 < 2; ++k16)
+#pragma unroll
+      for (int t = 6 - NT; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k16][PA[t] < NP ? PA[t] : 0][i], b[k16][PB[t] < NP ? PB[t] : 0],
+                                                           acc[i], 0, 0, 0);
+    __syncthreads();
+  }
+  const int m = m0 + wm * 32 + fr;
+  if (m < M) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (t < T) {
+          const size_t o = (size_t)t * M + m;
+          y[o] = resid ? resid[o] + acc[i][e] : acc[i][e];
+        }
+      }
+  }
+}
+
 // ---- producers of the activation planes ----------------------------------------------------------------------------
 // planes[p][t][k] bf16, t < Tpad (rows >= T are never written: a token row only ever meets its own output row)
 enum SplitMode { SPLIT_PLAIN = 0, SPLIT_RMSNORM = 1, SPLIT_SWIGLU = 2 };
@@ -313,6 +449,21 @@ int launch_gemm_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const f
   return 0;
 }
 
+template <int TYPE, int NP, int NT>
+int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  const int mtiles = (w.rows + 63) / 64, ntiles = (T + GB_N - 1) / GB_N;
+  constexpr size_t lds = gemm_lds_bytes<NP, 64>();
+  static bool attr = false;
+  if (!attr) {
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_ws_kernel<TYPE, NP, NT>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  gemm_q_ws_kernel<TYPE, NP, NT><<<dim3(mtiles * ntiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int TYPE, int BM>
 int launch_gemm_bm(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                    hipStream_t s) {
@@ -325,10 +476,17 @@ template <int TYPE>
 int launch_gemm_typed(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                       hipStream_t s) {
   // 128-row tiles when they still give every CU two workgroups' worth of tiles, else 64-row tiles
-  static int forced = -1;
+  static int forced = -1, ws = -1;
   if (forced < 0) {
     const char* e = getenv("TL_GEMM_BM");
     forced = e ? atoi(e) : 0;
+    const char* v = getenv("TL_GEMM_WS");
+    ws = v ? atoi(v) : 1;  // default: the wave-specialised kernel; TL_GEMM_WS=0 selects the unified one (A/B runs)
+  }
+  if (ws) {
+    if (terms == 1) return launch_gemm_ws<TYPE, 1, 1>(w, xp, ps, y, resid, T, s);
+    if (terms == 3) return launch_gemm_ws<TYPE, 2, 3>(w, xp, ps, y, resid, T, s);
+    return launch_gemm_ws<TYPE, 3, 6>(w, xp, ps, y, resid, T, s);
   }
   const long tiles128 = (long)((w.rows + 127) / 128) * ((T + GB_N - 1) / GB_N);
   const bool big = forced ? forced == 128 : tiles128 >= 2 * 256;

@@ -268,11 +268,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16
 // rows x 128 tokens x 32 columns per step), same two swizzled LDS buffers, one workgroup barrier per step.
 constexpr int WS_THREADS = 512;
 
-template <int TYPE, int NP, int NT>
+template <int TYPE, int NP, int NT, int BM>
 __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
                                                                float* __restrict__ y, const float* __restrict__ resid,
                                                                int T, int mtiles, int ntiles) {
-  constexpr int BM = 64;
+  constexpr int MI = BM / 64;  // weight rows per producer thread; 32-row fragments per consumer wave
   constexpr int WPL = BM * LROW, XPL = GB_N * LROW;
   constexpr int BUF = NP * (WPL + XPL);
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
@@ -288,12 +288,14 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     // ---------------- producers (waves 4-7: with round-robin wave placement one per SIMD, next to one consumer) ----------
     const int tid = threadIdx.x - 256;
     const int wrow = tid >> 2, wq = tid & 3;
-    const int grow = m0 + wrow < M ? m0 + wrow : M - 1;
+    int grow[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) grow[j] = m0 + wrow + 64 * j < M ? m0 + wrow + 64 * j : M - 1;
     const int xr0 = tid >> 2, xr1 = xr0 + 64, xs = tid & 3;
     const __bf16* xg0 = xp + (size_t)(n0 + xr0) * K + xs * 8;
     const __bf16* xg1 = xp + (size_t)(n0 + xr1) * K + xs * 8;
     struct Regs {
-      Raw8 rw;
+      Raw8 rw[MI];
       bf16x8 rx[NP][2];
     };
     // three register sets in rotation, the loop unrolled by three so that the rotation is register renaming and not
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     Regs s0, s1, s2;
     auto fetch = [&](Regs& g, int kn) {
       kn = kn < last ? kn : last;  // clamped, unconditional: the waits stay counted
-      g.rw = load8<TYPE>(w, grow, kn, wq);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) g.rw[j] = load8<TYPE>(w, grow[j], kn, wq);
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         g.rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride + (size_t)kn * GB_K);
@@ -313,13 +316,17 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
       kn = kn < last ? kn : last;
       __bf16* wb = lds + buf * BUF;
       __bf16* xb = wb + NP * WPL;
-      float wv[8];
-      deq8<TYPE>(g.rw, kn, wq, wv);
-      bf16x8 wp[NP];
-      split8<NP>(wv, wp);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+        float wv[8];
+        deq8<TYPE>(g.rw[j], kn, wq, wv);
+        bf16x8 wp[NP];
+        split8<NP>(wv, wp);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8*>(wb + p * WPL + lds_off(wrow + 64 * j, wq)) = wp[p];
+      }
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<bf16x8*>(wb + p * WPL + lds_off(wrow, wq)) = wp[p];
         *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0, xs)) = g.rx[p][0];
         *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr1, xs)) = g.rx[p][1];
       }
@@ -342,15 +349,17 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     }
     return;
   }
-  // ---------------- consumers ----------------
+  // ---------------- consumers: wave = 64 tokens x BM/2 rows ----------------
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int fr = lane & 31, fh = lane >> 5;
-  f32x16 acc[2];
+  f32x16 acc[2][MI];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   __syncthreads();
   for (int kk = 0; kk < nk3; ++kk) {
     if (kk >= nk) {  // uniform
@@ -359,28 +368,33 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     }
     const __bf16* wb = lds + (kk & 1) * BUF;
     const __bf16* xb = wb + NP * WPL;
-    bf16x8 a[2][NP][2], b[2][NP];
 #pragma unroll
-    for (int k16 = 0; k16 < 2; ++k16)
+    for (int k16 = 0; k16 < 2; ++k16) {
+      bf16x8 a[NP][2], b[NP][MI];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        a[k16][p][0] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + fr, k16 * 2 + fh));
-        a[k16][p][1] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 + fr, k16 * 2 + fh));
-        b[k16][p] = *reinterpret_cast<const bf16x8*>(wb + p * WPL + lds_off(wm * 32 + fr, k16 * 2 + fh));
-      }
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        a[p][0] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + fr, k16 * 2 + fh));
+        a[p][1] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 + fr, k16 * 2 + fh));
 #pragma unroll
-    for (int k16 = 0; k16 < 2; ++k16)
+        for (int j = 0; j < MI; ++j)
+          b[p][j] = *reinterpret_cast<const bf16x8*>(wb + p * WPL + lds_off(wm * (BM / 2) + 32 * j + fr, k16 * 2 + fh));
+      }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
       for (int t = 6 - NT; t < 6; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k16][PA[t] < NP ? PA[t] : 0][i], b[k16][PB[t] < NP ? PB[t] : 0],
-                                                           acc[i], 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < MI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t] < NP ? PA[t] : 0][i], b[PB[t] < NP ? PB[t] : 0][j],
+                                                                acc[i][j], 0, 0, 0);
+    }
     __syncthreads();
   }
-  const int m = m0 + wm * 32 + fr;
-  if (m < M) {
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + wm * (BM / 2) + 32 * j + fr;
+    if (m >= M) continue;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -388,7 +402,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
         const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (t < T) {
           const size_t o = (size_t)t * M + m;
-          y[o] = resid ? resid[o] + acc[i][e] : acc[i][e];
+          y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
         }
       }
   }
@@ -449,19 +463,26 @@ int launch_gemm_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const f
   return 0;
 }
 
-template <int TYPE, int NP, int NT>
+template <int TYPE, int NP, int NT, int BM>
 int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
-  const int mtiles = (w.rows + 63) / 64, ntiles = (T + GB_N - 1) / GB_N;
-  constexpr size_t lds = gemm_lds_bytes<NP, 64>();
+  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + GB_N - 1) / GB_N;
+  constexpr size_t lds = gemm_lds_bytes<NP, BM>();
   static bool attr = false;
   if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_ws_kernel<TYPE, NP, NT>),
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_ws_kernel<TYPE, NP, NT, BM>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  gemm_q_ws_kernel<TYPE, NP, NT><<<dim3(mtiles * ntiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  gemm_q_ws_kernel<TYPE, NP, NT, BM><<<dim3(mtiles * ntiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
   TL_HIP(hipGetLastError());
   return 0;
+}
+template <int TYPE, int BM>
+int launch_gemm_ws_bm(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
+                      hipStream_t s) {
+  if (terms == 1) return launch_gemm_ws<TYPE, 1, 1, BM>(w, xp, ps, y, resid, T, s);
+  if (terms == 3) return launch_gemm_ws<TYPE, 2, 3, BM>(w, xp, ps, y, resid, T, s);
+  return launch_gemm_ws<TYPE, 3, 6, BM>(w, xp, ps, y, resid, T, s);
 }
 
 template <int TYPE, int BM>
@@ -483,12 +504,12 @@ int launch_gemm_typed(const QW& w, const __bf16* xp, size_t ps, float* y, const 
     const char* v = getenv("TL_GEMM_WS");
     ws = v ? atoi(v) : 1;  // default: the wave-specialised kernel; TL_GEMM_WS=0 selects the unified one (A/B runs)
   }
-  if (ws) {
-    if (terms == 1) return launch_gemm_ws<TYPE, 1, 1>(w, xp, ps, y, resid, T, s);
-    if (terms == 3) return launch_gemm_ws<TYPE, 2, 3>(w, xp, ps, y, resid, T, s);
-    return launch_gemm_ws<TYPE, 3, 6>(w, xp, ps, y, resid, T, s);
-  }
   const long tiles128 = (long)((w.rows + 127) / 128) * ((T + GB_N - 1) / GB_N);
+  if (ws) {  // 128-row tiles halve the LDS fragment traffic per MFMA but leave one workgroup per CU: measured 14 % slower
+    const bool big = forced == 128;
+    return big ? launch_gemm_ws_bm<TYPE, 128>(w, xp, ps, y, resid, T, terms, s)
+               : launch_gemm_ws_bm<TYPE, 64>(w, xp, ps, y, resid, T, terms, s);
+  }
   const bool big = forced ? forced == 128 : tiles128 >= 2 * 256;
   return big ? launch_gemm_bm<TYPE, 128>(w, xp, ps, y, resid, T, terms, s)
              : launch_gemm_bm<TYPE, 64>(w, xp, ps, y, resid, T, terms, s);

@@ -38,7 +38,11 @@ typedef struct tl_model tl_model;     /* a whole model + KV cache + workspaces +
 /* ---- runtime: replaces the inline cudaSetDevice/cudaMalloc/cudaMemcpy/cudaFree/cudaStream*/
 /*      cublasCreate sites (215 of them) ---------------------------------------- */
 const char* tl_last_error(void);
-int tl_init(int device_ordinal);              /* hipSetDevice + sanity (gfx950 expected) */
+int tl_init(int device_ordinal);
+/* frees the workspaces that the operator-level entry points (tl_attention, tl_matmul_q, tl_sample_top_k_top_p) grow
+ * lazily per device; optional (the process exit frees them too). Those entry points share one workspace per device:
+ * calls that overlap on one device must be serialised by the caller (one host thread, as in the reference). */
+int tl_shutdown(void);              /* hipSetDevice + sanity (gfx950 expected) */
 int tl_device_count(int* count_out);
 int tl_malloc(void** dev_out, size_t bytes);  /* cudaMalloc sites e.g. gpu_initialization.cpp:91-531 */
 int tl_free(void* dev);

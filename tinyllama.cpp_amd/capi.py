@@ -32,6 +32,7 @@ SIGNATURES = {
     "tl_init": [C.c_int],
     "tl_device_count": [C.POINTER(C.c_int)],
     "tl_malloc": [C.POINTER(C.c_void_p), _sz],
+    "tl_shutdown": [],
     "tl_free": [_vp],
     "tl_memset": [_vp, C.c_int, _sz, _vp],
     "tl_memcpy_h2d": [_vp, _vp, _sz, _vp],

@@ -560,8 +560,8 @@ extern "C" int tl_gemm_set_terms(int terms) {
 
 // ---- operator-level batched mat-mul: Y[T][rows] = X[T][cols] W^T ----------------------------------------------------
 // T < 8 (or an FP32 matrix): T GEMV launches, each bit-identical to tl_matvec_q. Otherwise the MFMA kernel above with
-// the process-wide term count (tl_gemm_set_terms); the activation planes live in a lazily grown workspace, so
-// concurrent calls on different streams must not share it (one host thread per stream, as in the reference).
+// the process-wide term count (tl_gemm_set_terms); the activation planes live in the per-device operator workspace
+// (tl_scratch): calls that overlap on one device must be serialised by the caller (one host thread per stream).
 extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream) {
   TL_REQUIRE(w && x_dev && y_dev && num_tokens >= 0, "tl_matmul_q: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -570,19 +570,10 @@ extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev
       TL_TRY(tl_matvec_q(w, x_dev + (size_t)t * w->cols, y_dev + (size_t)t * w->rows, stream));
     return 0;
   }
-  static void* ws = nullptr;
-  static size_t ws_bytes = 0;
   const int terms = g_gemm_terms, np = planes_of_terms(terms);
-  const size_t ps = tl_gemm_padded_tokens(num_tokens) * (size_t)w->cols, need = ps * np * sizeof(__bf16);
-  if (need > ws_bytes) {
-    TL_HIP(hipDeviceSynchronize());
-    if (ws) TL_HIP(hipFree(ws));
-    ws = nullptr;
-    ws_bytes = 0;
-    TL_HIP(hipMalloc(&ws, need));
-    TL_HIP(hipMemsetAsync(ws, 0, need, s));
-    ws_bytes = need;
-  }
+  const size_t ps = tl_gemm_padded_tokens(num_tokens) * (size_t)w->cols;
+  void* ws = nullptr;
+  TL_TRY(tl_scratch(TL_SCRATCH_GEMM_PLANES, ps * np * sizeof(__bf16), &ws));
   TL_TRY(tl_launch_split(SPLIT_PLAIN, x_dev, nullptr, ws, ps, num_tokens, w->cols, terms, 0.f, s));
   return tl_launch_gemm_q(qw_view(w), ws, ps, y_dev, nullptr, num_tokens, terms, s);
 }

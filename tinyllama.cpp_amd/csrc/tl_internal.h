@@ -29,6 +29,10 @@ void tl_set_error(const char* fmt, ...);
     if (rc_ != 0) return rc_; \
   } while (0)
 
+// lazily grown per-(device, slot) workspace of the operator-level entry points (tl_runtime.hip)
+enum TlScratchSlot { TL_SCRATCH_ATTN = 0, TL_SCRATCH_GEMM_PLANES, TL_SCRATCH_SAMPLE_PROBS, TL_SCRATCH_SAMPLE_PARAMS };
+int tl_scratch(int slot, size_t bytes, void** out);
+
 // ---- device layout of one quantized matrix -----------------------------------------------------------
 // The GGUF blocks (quantization.h:57-124) are split at upload into 16-byte-aligned planes, row-major by
 // output row, so that one wave-wide 16 B/lane load is a contiguous, aligned 1 KiB and every lane's 16 B

@@ -940,10 +940,11 @@ static int prefill_head(tl_model* m, int T, hipStream_t s) {
   return enqueue_head(m, s);
 }
 
-static int prepare_prefill(tl_model* m, const int* tokens_host, int num_tokens, bool all_logits, hipStream_t s) {
+// the prompt's token ids on the device (buffer kept and grown across calls)
+static int upload_tokens(tl_model* m, const int* tokens_host, int num_tokens, hipStream_t s) {
   tl_model::Prefill& p = m->pf;
-  TL_TRY(ensure_prefill_ws(m, all_logits));
   if (p.toks_cap < num_tokens) {
+    TL_HIP(hipStreamSynchronize(s));
     if (p.toks) TL_HIP(hipFree(p.toks));
     p.toks = nullptr;
     p.toks_cap = 0;
@@ -952,6 +953,10 @@ static int prepare_prefill(tl_model* m, const int* tokens_host, int num_tokens, 
   }
   TL_HIP(hipMemcpyAsync(p.toks, tokens_host, sizeof(int) * (size_t)num_tokens, hipMemcpyHostToDevice, s));
   return 0;
+}
+static int prepare_prefill(tl_model* m, const int* tokens_host, int num_tokens, bool all_logits, hipStream_t s) {
+  TL_TRY(ensure_prefill_ws(m, all_logits));
+  return upload_tokens(m, tokens_host, num_tokens, s);
 }
 
 static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, int start_pos, float* last_logits_host,
@@ -1080,25 +1085,19 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   // (all-token logits of a vocabulary-sharded lm_head are not gathered: that request takes the token-by-token route)
   if (num_tokens >= m->prefill_min_batch && (m->tp == 1 || !all_logits_host))
     return prefill_batched(m, tokens_host, num_tokens, start_pos, last_logits_host, all_logits_host);
-  int* toks_dev = nullptr;
-  TL_HIP(hipMalloc(&toks_dev, sizeof(int) * (size_t)num_tokens));
-  hipError_t e = hipMemcpyAsync(toks_dev, tokens_host, sizeof(int) * (size_t)num_tokens, hipMemcpyHostToDevice, m->stream);
-  int rc = 0;
-  if (e == hipSuccess) rc = set_state(m, tokens_host[0], start_pos, 1.0f, nullptr, 0);
+  TL_TRY(upload_tokens(m, tokens_host, num_tokens, m->stream));
+  TL_TRY(set_state(m, tokens_host[0], start_pos, 1.0f, nullptr, 0));
   const size_t V = (size_t)m->cfg.vocab_size;
-  for (int i = 0; rc == 0 && e == hipSuccess && i < num_tokens; ++i) {
-    set_token_kernel<<<1, 1, 0, m->stream>>>(m->state, toks_dev, i);
-    if (m->no_graph) rc = enqueue_step(m);
-    else e = hipGraphLaunch(m->graph_exec, m->stream);
-    if (e == hipSuccess && all_logits_host)
-      e = hipMemcpyAsync(all_logits_host + (size_t)i * V, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream);
+  for (int i = 0; i < num_tokens; ++i) {
+    set_token_kernel<<<1, 1, 0, m->stream>>>(m->state, m->pf.toks, i);
+    if (m->no_graph) TL_TRY(enqueue_step(m));
+    else TL_HIP(hipGraphLaunch(m->graph_exec, m->stream));
+    if (all_logits_host)
+      TL_HIP(hipMemcpyAsync(all_logits_host + (size_t)i * V, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream));
   }
-  if (rc == 0 && e == hipSuccess && last_logits_host)
-    e = hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
-  hipFree(toks_dev);
-  if (rc != 0) return rc;
-  TL_HIP(e);
+  if (last_logits_host)
+    TL_HIP(hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
   return 0;
 }
 

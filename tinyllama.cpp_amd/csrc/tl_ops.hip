@@ -307,24 +307,15 @@ extern "C" int tl_attention(const float* q_dev, const float* k_cache_dev, const 
   TL_REQUIRE(current_seq_len > 0 && current_seq_len <= cache_max_seq_len, "tl_attention: seq_len %d outside (0,%d]",
              current_seq_len, cache_max_seq_len);
   if (tl_attn_split_supported(num_heads, cache_num_kv_heads, head_dim)) {
-    // operator-level calls share one lazily grown workspace per process (not for use under stream capture)
-    static float* ws = nullptr;
-    static size_t ws_floats = 0;
+    // split partials live in the per-device operator workspace (tl_scratch; not for use under stream capture)
+    void* ws = nullptr;
+    TL_TRY(tl_scratch(TL_SCRATCH_ATTN, tl_attn_ws_floats(num_heads, head_dim) * sizeof(float), &ws));
     AttnArgs a = {};
-    const size_t need = tl_attn_ws_floats(num_heads, head_dim);
-    if (need > ws_floats) {
-      TL_HIP(hipDeviceSynchronize());
-      if (ws) TL_HIP(hipFree(ws));
-      ws = nullptr;
-      ws_floats = 0;
-      TL_HIP(hipMalloc(&ws, need * sizeof(float)));
-      ws_floats = need;
-    }
     a.q = q_dev;
     a.kc = const_cast<float*>(k_cache_dev);
     a.vc = const_cast<float*>(v_cache_dev);
     a.out = out_dev;
-    a.ws = ws;
+    a.ws = static_cast<float*>(ws);
     a.nh = num_heads;
     a.nkv = cache_num_kv_heads;
     a.hd = head_dim;

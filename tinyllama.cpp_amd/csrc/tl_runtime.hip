@@ -4,6 +4,10 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "tl_internal.h"
 
 static thread_local char g_err[1024] = "";
@@ -79,5 +83,48 @@ extern "C" int tl_stream_sync(void* stream) {
 }
 extern "C" int tl_device_sync(void) {
   TL_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+// ---- workspaces of the operator-level entry points ------------------------------------------------------------------------
+// tl_attention (split partials), tl_matmul_q (activation planes) and tl_sample_top_k_top_p (probabilities, parameters)
+// need device memory beyond their arguments. One lazily grown allocation per (device, slot), handed out under a mutex;
+// growing synchronises the device first (an earlier launch may still read the old block). Calls that share a slot must
+// not overlap on one device: one host thread per stream, as in the reference. tl_shutdown() frees them.
+namespace {
+std::mutex g_scratch_mu;
+std::map<std::pair<int, int>, std::pair<void*, size_t>> g_scratch;
+}  // namespace
+
+int tl_scratch(int slot, size_t bytes, void** out) {
+  int dev = 0;
+  TL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  auto& e = g_scratch[{dev, slot}];
+  if (e.second < bytes) {
+    TL_HIP(hipDeviceSynchronize());
+    if (e.first) TL_HIP(hipFree(e.first));
+    e = {nullptr, 0};
+    void* p = nullptr;
+    TL_HIP(hipMalloc(&p, bytes));
+    TL_HIP(hipMemset(p, 0, bytes));
+    e = {p, bytes};
+  }
+  *out = e.first;
+  return 0;
+}
+
+extern "C" int tl_shutdown(void) {
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  int cur = 0;
+  TL_HIP(hipGetDevice(&cur));
+  for (auto& kv : g_scratch) {
+    if (!kv.second.first) continue;
+    TL_HIP(hipSetDevice(kv.first.first));
+    TL_HIP(hipDeviceSynchronize());
+    TL_HIP(hipFree(kv.second.first));
+  }
+  g_scratch.clear();
+  TL_HIP(hipSetDevice(cur));
   return 0;
 }

@@ -264,18 +264,11 @@ extern "C" int tl_sample_top_k_top_p(const float* logits_dev, int n, float tempe
   TL_REQUIRE(temperature < 0.05f || k <= SK_MAX,
              "tl_sample_top_k_top_p: effective top_k %d exceeds the device sampler's limit %d (use the host path)", k, SK_MAX);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  static float* scratch = nullptr;
-  static size_t scratch_n = 0;
-  static TlSampleParams* params = nullptr;
-  if (!params) TL_HIP(hipMalloc(&params, sizeof(TlSampleParams)));
-  if ((size_t)n > scratch_n) {
-    TL_HIP(hipDeviceSynchronize());
-    if (scratch) TL_HIP(hipFree(scratch));
-    scratch = nullptr;
-    scratch_n = 0;
-    TL_HIP(hipMalloc(&scratch, sizeof(float) * (size_t)n));
-    scratch_n = (size_t)n;
-  }
+  void *scratch_v = nullptr, *params_v = nullptr;  // per-device operator workspace (tl_scratch)
+  TL_TRY(tl_scratch(TL_SCRATCH_SAMPLE_PROBS, sizeof(float) * (size_t)n, &scratch_v));
+  TL_TRY(tl_scratch(TL_SCRATCH_SAMPLE_PARAMS, sizeof(TlSampleParams), &params_v));
+  float* scratch = static_cast<float*>(scratch_v);
+  TlSampleParams* params = static_cast<TlSampleParams*>(params_v);
   TlSampleParams h = {};
   h.temperature = temperature;
   h.top_k = top_k;

@@ -358,3 +358,37 @@ def test_quantize_q8_k_bit_exact(E, oracle):
     from tinyllama_cpp_amd.capi import TlError
     with pytest.raises(TlError):
         check(lib().tl_quantize_q8_k(xb.ptr, 100, ob.ptr, None))
+
+
+def test_model_with_q8k_tensors_and_f32_refusal(E, pkg, oracle):
+    """Q8_K matrices (in-memory only in the reference: its GGUF parser rejects them) mix with the other formats in one
+    model, through decode and the MFMA prefill; an F32 projection matrix is refused at load with a clear error."""
+    from tinyllama_cpp_amd.capi import TlError
+    S = pkg.synth
+    cfg, tensors = S.build_model("tiny", "q4_k_m", seed=4)
+    rng = np.random.default_rng(4)
+    for name in ("blk.1.ffn_up.weight", "blk.0.attn_k.weight", "blk.2.ffn_down.weight"):
+        t, a, r, c = tensors[name]
+        tensors[name] = (S.Q8_K, S.random_blocks(S.Q8_K, r * c // 256, rng, w_std=1.0 / np.sqrt(c)), r, c)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    toks = rng.integers(0, cfg["vocab"], 20).astype(np.int32)
+    last = m.prefill(toks, 0)
+    for pos, tok in enumerate(toks):
+        _, want = om.forward(om.lookup_embedding(int(tok)), pos)
+    assert close(last, want, LOGIT_TOL).all(), np.abs(last - want).max()
+    nxt = int(np.argmax(want))
+    got = m.generate_greedy(nxt, 20, 6, 1.0, history=[nxt])
+    tok, ids = nxt, []
+    for i in range(6):
+        _, lg = om.forward(om.lookup_embedding(tok), 20 + i)
+        tok = int(np.argmax(lg))
+        ids.append(tok)
+    assert got.tolist() == ids
+    m.free()
+    om.close()
+    t, a, r, c = tensors["blk.0.attn_v.weight"]
+    bad = E.Model(cfg)
+    with pytest.raises(TlError, match="ggml type 0"):
+        bad.set_tensor("blk.0.attn_v.weight", S.F32, oracle.dequantize(t, a).reshape(r, c).copy(), r, c)
+    bad.free()

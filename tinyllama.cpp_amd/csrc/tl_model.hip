@@ -57,6 +57,7 @@ struct tl_model {
   size_t kv_layer_elems = 0;
   // workspaces
   float *x = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *att = nullptr, *h = nullptr, *logits = nullptr;
+  float* h_up = nullptr;  // up projection of a gate/up pair stored in two different formats (two launches + SwiGLU)
   float* rope = nullptr;
   float* cand_v = nullptr;     // per-slice arg-max candidates (sampling)
   int* cand_i = nullptr;
@@ -169,7 +170,7 @@ extern "C" int tl_model_free(tl_model* m) {
   tl_qweight_free(m->tok);
   tl_qweight_free(m->out);
   if (m->comm) ncclCommDestroy(m->comm);
-  float* bufs[] = {m->out_norm, m->kv_base, m->x, m->xp, m->zeros, m->q, m->k, m->v, m->att, m->h, m->logits, m->rope};
+  float* bufs[] = {m->out_norm, m->kv_base, m->x, m->xp, m->zeros, m->q, m->k, m->v, m->att, m->h, m->h_up, m->logits, m->rope};
   for (float* b : bufs) hipFree(b);
   hipFree(m->state);
   hipFree(m->cand_v);
@@ -221,6 +222,11 @@ extern "C" int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, c
     TL_REQUIRE(layer >= 0 && layer < c.num_hidden_layers, "tl_model_set_tensor: layer %d out of range", layer);
     slot = &m->layers[layer].q[kind];
   }
+  // the engine's fused GEMV / MFMA launches read block formats only: an F32 matrix (which the reference would also
+  // accept, weight_management.cpp:732-960) is refused here, at load, not at the first step
+  TL_REQUIRE(type == TL_Q4_K || type == TL_Q6_K || type == TL_Q8_0 || type == TL_Q8_K,
+             "tl_model_set_tensor: kind %d has ggml type %d; the engine holds Q4_K, Q6_K, Q8_0 and Q8_K matrices (F32 only "
+             "for norm weights)", kind, type);
   TL_REQUIRE(rows == er && cols == ec,
              "tl_model_set_tensor: kind %d has shape %d x %d, config expects %d x %d (tp rank %d of %d: pass this rank's shard)",
              kind, rows, cols, er, ec, m->rank, m->tp);
@@ -400,7 +406,7 @@ static GemvArgs args_gate_up(tl_model* m, int l) {
   LayerW& L = m->layers[l];
   GemvArgs g = {};
   g.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), m->h};
-  g.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), nullptr};
+  g.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), m->h_up};  // (only written when gate and up differ in format)
   g.nseg = 2;
   g.pair = 1;
   g.cols = m->cfg.hidden_size;
@@ -697,6 +703,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->v, sizeof(float) * m->kv_dim));
   TL_HIP(hipMalloc(&m->att, sizeof(float) * (size_t)m->qd_l));
   TL_HIP(hipMalloc(&m->h, sizeof(float) * (size_t)m->I_l));
+  TL_HIP(hipMalloc(&m->h_up, sizeof(float) * (size_t)m->I_l));
   (void)I;
   TL_HIP(hipMalloc(&m->logits, sizeof(float) * V));
   TL_HIP(hipMalloc(&m->rope, sizeof(float) * P * m->head_dim));

@@ -232,24 +232,44 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   }
 }
 
-// out[h][:] = sum_s o_s e^(m_s - M) / (sum_s l_s e^(m_s - M) + 1e-9): one workgroup per head (operator-level API)
+// out[h][:] = sum_s o_s e^(m_s - M) / (sum_s l_s e^(m_s - M) + 1e-9): one workgroup per head (operator-level API).
+// The (max, sum) pairs of all splits are loaded in one go and the partial rows eight at a time (unrolled, clamped:
+// independent loads instead of one dependent round trip per split); the sums run in split order.
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ out, int hd,
                                                            int seq_len, const int* __restrict__ pos_dev) {
+  constexpr int NS = TL_ATTN_MAX_SPLITS;
   const int len = pos_dev ? *pos_dev + 1 : seq_len;
   const int SL = tl_attn_split_len(len);
   const int active = (len + SL - 1) / SL;
   const int h = blockIdx.x, d = threadIdx.x;
   if (d >= hd) return;
   const int recl = hd + 4;
-  const float* rec0 = ws + (size_t)h * TL_ATTN_MAX_SPLITS * recl;
+  const float* rec0 = ws + (size_t)h * NS * recl;
+  float ms[NS], ls[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const float* rec = rec0 + (size_t)(s < active ? s : active - 1) * recl;
+    ms[s] = rec[hd];
+    ls[s] = rec[hd + 1];
+  }
   float M = -INFINITY;
-  for (int s = 0; s < active; ++s) M = fmaxf(M, rec0[(size_t)s * recl + hd]);
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s < active) M = fmaxf(M, ms[s]);
   float L = 0.f, O = 0.f;
-  for (int s = 0; s < active; ++s) {
-    const float* rec = rec0 + (size_t)s * recl;
-    const float w = expf(rec[hd] - M);
-    L = fmaf(rec[hd + 1], w, L);
-    O = fmaf(rec[d], w, O);
+#pragma unroll
+  for (int s0 = 0; s0 < NS; s0 += 8) {
+    if (s0 >= active) break;
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = rec0[(size_t)(s0 + j < active ? s0 + j : active - 1) * recl + d];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < active) {
+        const float w = expf(ms[s0 + j] - M);
+        L = fmaf(ls[s0 + j], w, L);
+        O = fmaf(o[j], w, O);
+      }
   }
   out[(size_t)h * hd + d] = O * (1.0f / (L + 1e-9f));  // utils.cpp:692
 }

@@ -96,32 +96,59 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return 1
-    model = engine.Model(cfg, tp_rank=rank, tp_size=world)
-    if world > 1:  # rank 0 makes the communicator id, torch.distributed carries it to the other ranks
-        import torch
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(engine.tp_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, src=0)
-        model.tp_init(uid.cpu().numpy().tobytes())
-    elif os.environ.get("TL_TP_SELFTEST"):  # one-rank communicator: the RCCL calls of the step on a single GPU
-        model.tp_init(engine.tp_unique_id())
     keep = {}  # host copies kept for the CPU-baseline sample: first layers + globals
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
-    for name, typ, rows, cols in plan:
-        arr = S.make_tensor(name, typ, rows, cols, seed=42)
-        model.set_tensor(name, typ, arr, rows, cols)
-        layer = int(name.split(".")[1]) if name.startswith("blk.") else -1
-        if want_cpu and (layer < 0 or layer < args.cpu_layers):
-            keep[name] = (typ, arr, rows, cols)
-        del arr
-    model.finalize()
+
+    def build(tp_rank, tp_size):
+        model = engine.Model(cfg, tp_rank=tp_rank, tp_size=tp_size)
+        if tp_size > 1:  # rank 0 makes the communicator id, torch.distributed carries it to the other ranks
+            import torch
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(engine.tp_unique_id()), dtype=torch.uint8))
+            dist.broadcast(uid, src=0)
+            model.tp_init(uid.cpu().numpy().tobytes())
+        elif os.environ.get("TL_TP_SELFTEST"):  # one-rank communicator: the RCCL calls of the step on a single GPU
+            model.tp_init(engine.tp_unique_id())
+        for name, typ, rows, cols in plan:
+            arr = S.make_tensor(name, typ, rows, cols, seed=42)
+            model.set_tensor(name, typ, arr, rows, cols)
+            layer = int(name.split(".")[1]) if name.startswith("blk.") else -1
+            if want_cpu and (layer < 0 or layer < args.cpu_layers):
+                keep[name] = (typ, arr, rows, cols)
+            del arr
+        model.finalize()
+        return model
+
+    tp_fallback = None
+    if world == 1:
+        model = build(0, 1)
+    else:
+        # tensor parallel over the ranks. If the group cannot be set up (an exception on any rank, agreed on through
+        # torch.distributed), every rank falls back to a whole-model replica and the line says so: weak scaling, no
+        # exchange, labelled as a fallback. (A hang inside a collective cannot be caught this way.)
+        import torch
+        model, err = None, ""
+        try:
+            model = build(rank, world)
+        except Exception as e:
+            err = str(e)[:200]
+        ok = torch.tensor([0 if err else 1], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            tp_fallback = next((e for e in errs if e), "unknown")
+            if model is not None:
+                model.free()
+            model = build(0, 1)
     t_load = time.time() - t_load
 
     # ---- prompt (token by token: P < 32), then warm-up and the timed region --------------------------------
     prompt = np.random.default_rng(0).integers(0, cfg["vocab"], args.prompt_len)
     nxt = 0
-    if len(prompt) >= 32 and world == 1:  # the generate loop's rule (api.cpp:601): batched prefill from 32 tokens on
+    tp_world = 1 if (world == 1 or tp_fallback) else world  # ranks that share ONE sequence
+    if len(prompt) >= 32 and tp_world == 1:  # the generate loop's rule (api.cpp:601): batched prefill from 32 tokens on
         nxt = int(np.argmax(model.prefill(prompt.astype(np.int32), 0)))
     else:
         for pos, tok in enumerate(prompt):
@@ -149,7 +176,7 @@ def main():
     assert len(ids) == args.steps and all(0 <= int(i) < cfg["vocab"] for i in ids)
     mid_pos = pos + args.steps // 2
     w_bytes, kv_bytes = model.bytes_per_token(mid_pos)
-    tok_s = args.steps / dt
+    tok_s = args.steps / dt * (world if tp_fallback else 1)  # replicas (fallback): every rank decodes its own sequence
 
     # ---- the dominant kernel (fused RMSNorm + ffn_gate/ffn_up GEMV + SwiGLU): average launch duration with HIP events
     #      on the engine's stream, back-to-back launches cycling through the layers (every launch streams from HBM);
@@ -177,13 +204,15 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if tp_fallback else "strong",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic random-init weights (GGUF block formats), fixed token-id prompt",
         "config": {"workload": f"{args.workload} {mix} greedy decode, batch 1, prompt {args.prompt_len}, "
                                f"positions {pos}..{pos + args.steps - 1}, f32 KV cache",
                    "parallelism": "single GPU" if world == 1 else
+                                  f"FALLBACK: {world} whole-model replicas, no exchange (tensor-parallel set-up failed: {tp_fallback})"
+                                  if tp_fallback else
                                   f"tp{world}: row/column-split projections, 2 RCCL all-reduces of f32[{cfg['hidden']}] "
                                   f"per layer + logits all-gather, "
                                   f"{'inside the captured step graph' if model.graph_captured() else 'eager launches (capture refused)'}",
@@ -205,7 +234,7 @@ def main():
     # (under tensor parallelism every rank runs it: the prefill's all-reduces are collective calls)
     if cfg["max_pos"] >= 512 + 8 and not args.no_prefill_leg:
         try:
-            out["prefill"] = prefill_leg(model, S, cfg, mix, 512, world=world)
+            out["prefill"] = prefill_leg(model, S, cfg, mix, 512, world=tp_world)
         except Exception as e:  # the decode numbers above stay valid
             out["prefill"] = {"error": str(e)[:300]}
 

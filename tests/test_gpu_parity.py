@@ -178,7 +178,8 @@ def test_rope_table_upload_matches_oracle(E, oracle):
         assert np.array_equal(b.to_numpy(np.float32, (n, hd // 2, 2)), oracle.rope_table(n, hd, theta))
 
 
-@pytest.mark.parametrize("nh,nkv,hd,npos", [(4, 2, 64, 1), (32, 4, 64, 77), (32, 8, 128, 300), (8, 8, 128, 2048)])
+@pytest.mark.parametrize("nh,nkv,hd,npos", [(4, 2, 64, 1), (32, 4, 64, 77), (32, 8, 128, 300), (8, 8, 128, 2048),
+                                            (64, 8, 128, 700), (32, 4, 64, 1500), (24, 8, 128, 33)])
 def test_attention_decode_and_prefill(E, oracle, nh, nkv, hd, npos):
     from tinyllama_cpp_amd.capi import lib, check
     rng = np.random.default_rng(nh + npos)

@@ -108,3 +108,31 @@ def test_tp_local_group_prefill_matches_oracle(pkg, oracle, shape, mix, tp, T):
     for m in shards:
         m.free()
     om.close()
+
+
+def test_tp8_at_the_70b_shard_shapes(pkg, oracle):
+    """BASELINE config 5 (Llama-3-70B-shaped, TP = 8) at its real per-rank shapes — hidden 8192, 8 query heads + 1 kv head
+    and 3584 intermediate columns per rank — cut to 2 layers and a 4096-token vocabulary so that the CPU oracle can
+    follow: decode in lockstep over all 8 shards on one GPU, then a batched prefill."""
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg = dict(pkg.synth.SHAPES["llama-3-70b"], n_layers=2, vocab=4096, max_pos=64)
+    cfg, tensors = pkg.synth.build_model(cfg, "q4_k_m", seed=70)
+    shards = [E.Model(cfg, tp_rank=r, tp_size=8).load(tensors) for r in range(8)]
+    om = OracleModel(oracle, cfg, tensors)
+    toks = np.random.default_rng(70).integers(0, cfg["vocab"], 4).astype(np.int32)
+    for pos, tok in enumerate(toks):
+        _, want = om.forward(om.lookup_embedding(int(tok)), pos)
+        logits, nxt = E.tp_local_group_decode(shards, int(tok), pos)
+        assert close(logits, want, LOGIT_TOL).all(), (pos, np.abs(logits - want).max())
+        assert nxt == int(np.argmax(want))
+    ptoks = np.random.default_rng(71).integers(0, cfg["vocab"], 24).astype(np.int32)
+    for m in shards:
+        m.reset_kv()
+    om.reset_kv()
+    _, lb = om.forward_batch(np.stack([om.lookup_embedding(t) for t in ptoks]), 0)
+    last = E.tp_local_group_prefill(shards, ptoks, 0)
+    assert close(last, lb[-1], LOGIT_TOL).all(), np.abs(last - lb[-1]).max()
+    for m in shards:
+        m.free()
+    om.close()

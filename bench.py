@@ -108,6 +108,21 @@ def main():
                 uid.copy_(torch.frombuffer(bytearray(engine.tp_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, src=0)
             model.tp_init(uid.cpu().numpy().tobytes())
+            # the decode step's 16 KB exchanges: one-shot peer-to-peer kernels over hipIpc-mapped areas (csrc/tl_peer.hip)
+            # when every rank passes their self-check, else the RCCL calls (TL_TP_PEER=0 forces those)
+            if os.environ.get("TL_TP_PEER", "1") != "0":
+                def gather(b):
+                    mine = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+                    parts = [torch.empty_like(mine) for _ in range(tp_size)]
+                    dist.all_gather(parts, mine)
+                    return [p_.cpu().numpy().tobytes() for p_ in parts]
+
+                def agree(flag):
+                    t = torch.tensor([1 if flag else 0], device="cuda")
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                    return bool(int(t.item()))
+
+                pkg_tp.peer_link(model, gather, agree)
         elif os.environ.get("TL_TP_SELFTEST"):  # one-rank communicator: the RCCL calls of the step on a single GPU
             model.tp_init(engine.tp_unique_id())
         for name, typ, rows, cols in plan:
@@ -187,6 +202,9 @@ def main():
     for k in ("qkv_gemv", "attn_out_gemv", "gate_up_gemv", "down_gemv", "lm_head_gemv"):
         us, nb = model.bench_kernel(k, iters=64 if k == "lm_head_gemv" else 4 * cfg["n_layers"], warmup=8)
         kern[k] = {"us": round(us, 2), "gbps": round(nb / (us * 1e-6) / 1e9, 1)}
+    if tp_world > 1:  # the step's all-reduce of f32[hidden], back to back on every rank (2 per layer in a step)
+        us, nb = model.bench_kernel("tp_all_reduce", iters=500, warmup=50)
+        kern["tp_all_reduce"] = {"us": round(us, 2), "bytes": int(nb), "via": "peer" if model.tp_peer_enabled() else "rccl"}
     # whole eager steps with an event after every launch (includes ~5 us of event overhead per launch; the GEMV rows
     # above are the clean numbers): kept for the non-GEMV kernels
     prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
@@ -213,8 +231,9 @@ def main():
                    "parallelism": "single GPU" if world == 1 else
                                   f"FALLBACK: {world} whole-model replicas, no exchange (tensor-parallel set-up failed: {tp_fallback})"
                                   if tp_fallback else
-                                  f"tp{world}: row/column-split projections, 2 RCCL all-reduces of f32[{cfg['hidden']}] "
-                                  f"per layer + logits all-gather, "
+                                  f"tp{world}: row/column-split projections, 2 all-reduces of f32[{cfg['hidden']}] "
+                                  f"per layer + logits all-gather "
+                                  f"({'one-shot peer-to-peer exchange kernels over xGMI (hipIpc-mapped areas)' if model.tp_peer_enabled() else 'RCCL'}), "
                                   f"{'inside the captured step graph' if model.graph_captured() else 'eager launches (capture refused)'}",
                    "weight_bytes_per_token_per_gpu": int(w_bytes), "kv_bytes_per_token_mid_per_gpu": int(kv_bytes)},
         # per GPU: every rank streams its own 1/N of the bytes in the same step time

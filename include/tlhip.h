@@ -203,7 +203,8 @@ int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_s
                             int* kind_launches_out);
 /* Measurement hook (no counterpart in the reference): `iters` back-to-back launches of ONE kind of the decode step's
  * GEMV kernels (kinds as above: 1, 4, 5, 6, 7), cycling through the layers so that every launch streams from HBM,
- * timed with HIP events on the engine's stream. Leaves activations / logits in an unspecified state. */
+ * timed with HIP events on the engine's stream. Leaves activations / logits in an unspecified state. kind 9: the
+ * step's all-reduce of f32[hidden] of a linked tensor-parallel shard (a collective call: every rank makes it). */
 int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* avg_us_out, double* bytes_per_launch_out);
 /* device pointers into the model's state, for parity tests and for hosts that keep using the operator-level
  * calls: which = 0 K cache, 1 V cache of `layer` ([max_pos][n_kv_heads_local][head_dim] f32), 2 = x (hidden) */
@@ -216,6 +217,20 @@ int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, d
  * captured into the graph there. Replaces distributed_coordinator.cpp's MPI request routing. */
 int tl_tp_unique_id(void* id_out_128);
 int tl_model_tp_init(tl_model* m, const void* unique_id_128);
+/* Peer-to-peer exchange for the decode step (no counterpart in the reference): the two f32[hidden] all-reduces per layer
+ * and the logits all-gather of a tp_size 2..8 group as ONE small kernel each, which pushes 8-byte {value, epoch} words
+ * straight into receive areas that every rank maps from every other rank (hipIpc; xGMI links between the GPUs of a
+ * node) and sums what arrives in rank order. Wiring, on every rank, before tl_model_finalize:
+ *   tl_model_tp_peer_export  -> this rank's 64-byte IPC handle; the host gathers the handles of all ranks (rank order)
+ *   tl_model_tp_peer_import  -> maps them and runs a COLLECTIVE self-check (known sums); *ok_out = 1 if it passed here
+ *   the host agrees on min(ok) over the ranks and calls tl_model_tp_peer_enable(m, agreed) on every rank.
+ * Enabled: the decode step uses the peer kernels (the batched prefill's T x hidden all-reduces stay with RCCL and need
+ * tl_model_tp_init; without a communicator a sharded prefill goes token by token). Every poll is bounded (5 s, or
+ * TL_TP_PEER_TIMEOUT_MS): a missing rank turns into an error return of the decode / generate call, not a hang. */
+int tl_model_tp_peer_export(tl_model* m, void* handle_out_64);
+int tl_model_tp_peer_import(tl_model* m, const void* handles_tp_x_64, int* ok_out);
+int tl_model_tp_peer_enable(tl_model* m, int on);
+int tl_model_tp_peer_enabled(const tl_model* m, int* on_out);
 /* Diagnostic (no counterpart in the reference): *captured_out = 1 when the decode step replays as one hipGraph, 0 when
  * it is enqueued launch by launch (TL_NO_GRAPH=1, a shard without a communicator, or a collective that refused
  * capture). With TL_TP_SELFTEST=1 in the environment tl_model_tp_init gives a tp_size-1 model a one-rank communicator,

@@ -1,0 +1,63 @@
+"""The peer-to-peer exchange of the tensor-parallel decode step (csrc/tl_peer.hip) between SEPARATE PROCESSES: tp worker
+processes share GPU 0, map each other's receive areas through hipIpc handles, pass the collective self-check and decode
+one sequence, every process replaying its own captured step graph. On one device the words cross between processes (and
+between the 8 L2s of the chip) instead of xGMI links; protocol, epochs, slot reuse, bounded polls and the wiring are the
+same code that bench.py --gpus N runs. Results vs the unsharded CPU oracle; all ranks must agree bit for bit."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleModel
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
+
+
+@pytest.mark.parametrize("shape,mix,tp", [("tiny-gqa", "q4_k_m", 2), ("tiny-tp", "q4_k_m", 4)])
+def test_peer_linked_processes_match_oracle(pkg, oracle, tmp_path, shape, mix, tp):
+    env = dict(os.environ, TL_TP_PEER_TIMEOUT_MS="4000")
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_tp_peer_worker.py"), str(r), str(tp), shape, mix,
+                               str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(tp)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            outs.append(out.decode(errors="replace")[-2000:])
+    finally:
+        for p in procs:  # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(f"rank {i} rc {p.returncode}\n{o}" for i, (p, o) in enumerate(zip(procs, outs)))
+    res = [dict(np.load(os.path.join(tmp_path, f"result_{r}.npz"))) for r in range(tp)]
+    for r in res:
+        assert bool(r["linked"]) and bool(r["peer"]) and bool(r["captured"])
+    cfg, tensors = pkg.synth.build_model(shape, mix, seed=5)
+    om = OracleModel(oracle, cfg, tensors)
+    toks = np.random.default_rng(2).integers(0, cfg["vocab"], 9).astype(np.int32)
+    om.reset_kv()
+    want = np.stack([om.forward(om.lookup_embedding(int(t)), pos)[1] for pos, t in enumerate(toks)])
+    assert close(res[0]["logits"], want, LOGIT_TOL).all(), np.abs(res[0]["logits"] - want).max()
+    tok, ids = int(np.argmax(want[-1])), []
+    for i in range(24):
+        _, lg = om.forward(om.lookup_embedding(tok), len(toks) + i)
+        tok = int(np.argmax(lg))
+        ids.append(tok)
+    assert np.array_equal(res[0]["ids"], np.array(ids, np.int32))
+    om.reset_kv()
+    ptoks = np.random.default_rng(3).integers(0, cfg["vocab"], 40).astype(np.int32)
+    _, lb = om.forward_batch(np.stack([om.lookup_embedding(t) for t in ptoks]), 0)
+    assert close(res[0]["last"], lb[-1], LOGIT_TOL).all()
+    for r in res[1:]:  # the rank-ordered sums make every rank's results identical
+        assert np.array_equal(r["logits"], res[0]["logits"]) and np.array_equal(r["ids"], res[0]["ids"])
+        assert np.array_equal(r["last"], res[0]["last"])
+    om.close()

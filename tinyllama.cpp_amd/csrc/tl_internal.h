@@ -167,3 +167,16 @@ int tl_launch_sample_topk(float* logits, int n, float* probs_scratch, int* state
 
 int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, const int* n_hist_dev, float penalty,
                      hipStream_t s);
+
+// ---- tl_peer.hip: one-shot peer-to-peer exchange for the tensor-parallel decode step (hipIpc-mapped receive areas,
+//      8-byte {value, epoch} words, bounded polls). tl_peer_create makes this rank's area and its 64-byte IPC handle;
+//      tl_peer_connect takes the handles of all tp ranks (rank order); tl_peer_selftest is collective.
+constexpr int TL_PEER_MAX_RANKS = 8;
+struct TlPeer;
+int tl_peer_create(int tp, int rank, int n_reduce, int n_gather, TlPeer** out, void* handle_out_64);
+int tl_peer_connect(TlPeer* p, const void* handles);
+int tl_peer_selftest(TlPeer* p, hipStream_t s, int* ok_out);
+int tl_peer_all_reduce(TlPeer* p, const float* in, float* out, hipStream_t s);
+int tl_peer_all_gather(TlPeer* p, float* buf, hipStream_t s);
+int tl_peer_error_async(TlPeer* p, unsigned* flag_host, hipStream_t s);
+void tl_peer_destroy(TlPeer* p);

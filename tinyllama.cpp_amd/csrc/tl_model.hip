@@ -48,6 +48,11 @@ struct tl_model {
   float* zeros = nullptr;  // tp > 1: the 'residual' of ranks != 0
   bool allocated = false;  // buffers exist (set by tl_model_finalize, also when the graph is skipped)
   ncclComm_t comm = nullptr;
+  // tp > 1: one-shot peer-to-peer exchange (tl_peer.hip) for the decode step's 16 KB all-reduces and the logits
+  // all-gather, used instead of the RCCL calls once every rank's self-check passed (tl_model_tp_peer_enable)
+  TlPeer* peer = nullptr;
+  bool peer_on = false;
+  bool linked() const { return comm != nullptr || peer_on; }  // this shard can exchange with the rest of its group
   std::vector<LayerW> layers;
   tl_qweight* tok = nullptr;
   tl_qweight* out = nullptr;
@@ -170,6 +175,7 @@ extern "C" int tl_model_free(tl_model* m) {
   tl_qweight_free(m->tok);
   tl_qweight_free(m->out);
   if (m->comm) ncclCommDestroy(m->comm);
+  tl_peer_destroy(m->peer);
   float* bufs[] = {m->out_norm, m->kv_base, m->x, m->xp, m->zeros, m->q, m->k, m->v, m->att, m->h, m->h_up, m->logits, m->rope};
   for (float* b : bufs) hipFree(b);
   hipFree(m->state);
@@ -450,9 +456,31 @@ static GemvArgs args_lm_head(tl_model* m) {
 // x = sum over ranks of xp (RCCL over xGMI; one f32[hidden_size] all-reduce per row-split projection)
 static int tp_all_reduce(tl_model* m, hipStream_t s) {
   if (m->tp == 1 && !m->comm) return 0;
+  if (m->peer_on) return tl_peer_all_reduce(m->peer, m->xp, m->x, s);
   TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
   // (tp == 1 with a communicator is the one-rank self-test of tl_model_tp_init: in place on x)
   TL_NCCL(ncclAllReduce(m->tp > 1 ? m->xp : m->x, m->x, (size_t)m->cfg.hidden_size, ncclFloat, ncclSum, m->comm, s));
+  return 0;
+}
+
+// every rank gets the full logits (in place: its own vocabulary rows already sit at rank * V_l) and samples
+static int tp_gather_logits(tl_model* m, hipStream_t s) {
+  if (m->tp == 1 && !m->comm) return 0;
+  if (m->peer_on) return tl_peer_all_gather(m->peer, m->logits, s);
+  TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
+  TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
+  return 0;
+}
+// after a synchronised run: did a peer exchange give up waiting (a rank of the group is gone or out of step)?
+static int tp_check_peer(tl_model* m) {
+  if (!m->peer_on) return 0;
+  unsigned flag = 0;
+  TL_TRY(tl_peer_error_async(m->peer, &flag, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  if (flag != 0) {
+    tl_set_error("tl_model: a peer-to-peer exchange timed out waiting for another rank of the tensor-parallel group");
+    return 5;
+  }
   return 0;
 }
 
@@ -529,10 +557,7 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr, bool sampled = fa
     PROF_MARK(6);
   }
   TL_TRY(enqueue_head(m, s));
-  if (m->tp > 1 || m->comm) {  // every rank gets the full logits (in place: its own rows already sit at rank * V_l) and samples
-    TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
-    TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
-  }
+  TL_TRY(tp_gather_logits(m, s));
   PROF_MARK(7);
   if (sampled) TL_TRY(enqueue_sample_topk(m, s));
   else TL_TRY(enqueue_sample(m, s));
@@ -624,7 +649,26 @@ extern "C" int tl_tp_local_group_decode(tl_model* const* ms, int n, int token_id
 extern "C" int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* avg_us_out,
                                      double* bytes_per_launch_out) {
   TL_REQUIRE(m && m->finalized && iters > 0 && warmup >= 0 && avg_us_out, "tl_model_bench_kernel: bad argument");
-  TL_REQUIRE(kind == 1 || kind == 4 || kind == 5 || kind == 6 || kind == 7, "tl_model_bench_kernel: kind %d", kind);
+  TL_REQUIRE(kind == 1 || kind == 4 || kind == 5 || kind == 6 || kind == 7 || kind == 9, "tl_model_bench_kernel: kind %d", kind);
+  if (kind == 9) {  // the step's all-reduce of f32[hidden] (COLLECTIVE: every rank of the group makes the same call)
+    TL_REQUIRE(m->tp > 1 && m->linked(), "tl_model_bench_kernel: kind 9 needs a linked tensor-parallel shard");
+    hipStream_t s = m->stream;
+    hipEvent_t e0, e1;
+    TL_HIP(hipEventCreate(&e0));
+    TL_HIP(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) TL_TRY(tp_all_reduce(m, s));
+    TL_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) TL_TRY(tp_all_reduce(m, s));
+    TL_HIP(hipEventRecord(e1, s));
+    TL_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    TL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_us_out = ms * 1e3f / iters;
+    if (bytes_per_launch_out) *bytes_per_launch_out = sizeof(float) * (double)m->cfg.hidden_size;
+    return tp_check_peer(m);
+  }
   const int L = m->cfg.num_hidden_layers;
   auto args_of = [&](int i) {
     const int l = i % L;
@@ -716,7 +760,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->state, sizeof(int) * (kStateHeaderInts + m->hist_cap)));
   TL_HIP(hipMemsetAsync(m->state, 0, sizeof(int) * (kStateHeaderInts + m->hist_cap), m->stream));
   m->allocated = true;
-  if (m->tp > 1 && !m->comm) {
+  if (m->tp > 1 && !m->linked()) {
     // a shard without a communicator: only usable through tl_tp_local_group_decode (all shards in one process)
     TL_HIP(hipStreamSynchronize(m->stream));
     m->no_graph = true;
@@ -734,7 +778,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
     hipError_t e = hipStreamEndCapture(m->stream, &m->graph);
     if (rc == 0 && e == hipSuccess) e = hipGraphInstantiate(&m->graph_exec, m->graph, nullptr, nullptr, 0);
     if (rc != 0 || e != hipSuccess) {
-      if (!m->comm) {
+      if (!m->comm || m->peer_on) {
         if (rc != 0) return rc;
         TL_HIP(e);
       }
@@ -760,7 +804,7 @@ extern "C" int tl_model_reset_kv(tl_model* m) {
 
 extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits_host, int* next_token_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_decode: model not finalized");
-  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_decode: a shard without a communicator runs only in tl_tp_local_group_decode");
+  TL_REQUIRE(m->tp == 1 || m->linked(), "tl_model_decode: a shard without a communicator runs only in tl_tp_local_group_decode");
   TL_REQUIRE(pos >= 0 && pos < m->cfg.max_position_embeddings, "tl_model_decode: pos %d outside [0,%d)", pos,
              m->cfg.max_position_embeddings);
   TL_TRY(set_state(m, token_id, pos, 1.0f, nullptr, 0));
@@ -770,13 +814,13 @@ extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits
     TL_HIP(hipMemcpyAsync(logits_host, m->logits, sizeof(float) * (size_t)m->cfg.vocab_size, hipMemcpyDeviceToHost, m->stream));
   if (next_token_host) TL_HIP(hipMemcpyAsync(next_token_host, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
-  return 0;
+  return tp_check_peer(m);
 }
 
 extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_pos, int n_steps, float penalty,
                                         const int* history_host, int n_history, int* out_ids_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_generate_greedy: model not finalized");
-  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_generate_greedy: a shard without a communicator runs only in tl_tp_local_group_decode");
+  TL_REQUIRE(m->tp == 1 || m->linked(), "tl_model_generate_greedy: a shard without a communicator runs only in tl_tp_local_group_decode");
   TL_REQUIRE(n_steps >= 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
              "tl_model_generate_greedy: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + n_steps,
              m->cfg.max_position_embeddings);
@@ -793,7 +837,7 @@ extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_
     TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
                           hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
-  return 0;
+  return tp_check_peer(m);
 }
 
 // Sampled generation entirely on the device: the decode step with tl_sample.hip's top-k / top-p sampler as
@@ -803,7 +847,7 @@ extern "C" int tl_model_generate_sampled(tl_model* m, int first_token, int start
                                          const int* history_host, int n_history, float temperature, int top_k,
                                          float top_p, unsigned long long seed, int* out_ids_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_generate_sampled: model not finalized");
-  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_generate_sampled: a shard without a communicator cannot step alone");
+  TL_REQUIRE(m->tp == 1 || m->linked(), "tl_model_generate_sampled: a shard without a communicator cannot step alone");
   TL_REQUIRE(n_steps >= 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
              "tl_model_generate_sampled: positions [%d,%d) exceed max_position_embeddings %d", start_pos,
              start_pos + n_steps, m->cfg.max_position_embeddings);
@@ -845,7 +889,7 @@ extern "C" int tl_model_generate_sampled(tl_model* m, int first_token, int start
     TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
                           hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
-  return 0;
+  return tp_check_peer(m);
 }
 
 // ---- batched prefill (forward_device_batch_prefill model.cpp:1526-1862; math of CPUBatchProcessor::forward_cpu_batch,
@@ -991,14 +1035,13 @@ static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, 
     }
     if (c0 + T == num_tokens) {
       TL_TRY(prefill_head(m, T, s));
-      if (m->tp > 1)
-        TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
+      TL_TRY(tp_gather_logits(m, s));
       if (last_logits_host)
         TL_HIP(hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, s));
     }
   }
   TL_HIP(hipStreamSynchronize(s));
-  return 0;
+  return tp_check_peer(m);
 }
 
 // The batched prefill of a whole tensor-parallel group inside ONE process on ONE device (test hook, as above).
@@ -1084,13 +1127,15 @@ extern "C" int tl_model_set_prefill(tl_model* m, int terms, int min_batch) {
 extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tokens, int start_pos,
                                 float* last_logits_host, float* all_logits_host) {
   TL_REQUIRE(m && m->finalized, "tl_model_prefill: model not finalized");
-  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_prefill: a shard without a communicator runs only in tl_tp_local_group_decode");
+  TL_REQUIRE(m->tp == 1 || m->linked(), "tl_model_prefill: a shard without a communicator runs only in tl_tp_local_group_decode");
   TL_REQUIRE(tokens_host && num_tokens > 0, "tl_model_prefill: empty prompt");
   TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m->cfg.max_position_embeddings,
              "tl_model_prefill: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + num_tokens,
              m->cfg.max_position_embeddings);
   // (all-token logits of a vocabulary-sharded lm_head are not gathered: that request takes the token-by-token route)
-  if (num_tokens >= m->prefill_min_batch && (m->tp == 1 || !all_logits_host))
+  // (the T x hidden all-reduces of a sharded batched prefill are bandwidth-sized: they stay with RCCL; a group that is
+  //  linked by the peer exchange only takes the token-by-token route too)
+  if (num_tokens >= m->prefill_min_batch && (m->tp == 1 || (!all_logits_host && m->comm)))
     return prefill_batched(m, tokens_host, num_tokens, start_pos, last_logits_host, all_logits_host);
   TL_TRY(upload_tokens(m, tokens_host, num_tokens, m->stream));
   TL_TRY(set_state(m, tokens_host[0], start_pos, 1.0f, nullptr, 0));
@@ -1105,13 +1150,13 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   if (last_logits_host)
     TL_HIP(hipMemcpyAsync(last_logits_host, m->logits, sizeof(float) * V, hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
-  return 0;
+  return tp_check_peer(m);
 }
 
 extern "C" int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_steps, float* kind_ms_out,
                                        int* kind_launches_out) {
   TL_REQUIRE(m && m->finalized && kind_ms_out && kind_launches_out, "tl_model_profile_decode: bad argument");
-  TL_REQUIRE(m->tp == 1 || m->comm, "tl_model_profile_decode: a shard without a communicator cannot step alone");
+  TL_REQUIRE(m->tp == 1 || m->linked(), "tl_model_profile_decode: a shard without a communicator cannot step alone");
   TL_REQUIRE(n_steps > 0 && start_pos >= 0 && start_pos + n_steps <= m->cfg.max_position_embeddings,
              "tl_model_profile_decode: positions out of range");
   for (int k = 0; k < 9; ++k) {
@@ -1186,3 +1231,31 @@ extern "C" int tl_model_tp_init(tl_model* m, const void* unique_id_128) {
   return 0;
 }
 
+
+// ---- peer-to-peer exchange wiring (tl_peer.hip) ------------------------------------------------------------------------
+extern "C" int tl_model_tp_peer_export(tl_model* m, void* handle_out_64) {
+  TL_REQUIRE(m && handle_out_64, "tl_model_tp_peer_export: null argument");
+  TL_REQUIRE(!m->finalized, "tl_model_tp_peer_export: call before tl_model_finalize (the decode graph captures the exchanges)");
+  TL_REQUIRE(m->tp >= 2 && m->tp <= TL_PEER_MAX_RANKS, "tl_model_tp_peer_export: tp_size %d outside 2..%d", m->tp,
+             TL_PEER_MAX_RANKS);
+  TL_REQUIRE(!m->peer, "tl_model_tp_peer_export: already exported");
+  return tl_peer_create(m->tp, m->rank, m->cfg.hidden_size, m->V_l, &m->peer, handle_out_64);
+}
+extern "C" int tl_model_tp_peer_import(tl_model* m, const void* handles, int* ok_out) {
+  TL_REQUIRE(m && handles && ok_out, "tl_model_tp_peer_import: null argument");
+  TL_REQUIRE(m->peer && !m->finalized, "tl_model_tp_peer_import: call after tl_model_tp_peer_export and before tl_model_finalize");
+  *ok_out = 0;
+  TL_TRY(tl_peer_connect(m->peer, handles));
+  return tl_peer_selftest(m->peer, m->stream, ok_out);
+}
+extern "C" int tl_model_tp_peer_enable(tl_model* m, int on) {
+  TL_REQUIRE(m && !m->finalized, "tl_model_tp_peer_enable: call before tl_model_finalize");
+  TL_REQUIRE(!on || m->peer, "tl_model_tp_peer_enable: nothing imported");
+  m->peer_on = on != 0;
+  return 0;
+}
+extern "C" int tl_model_tp_peer_enabled(const tl_model* m, int* on_out) {
+  TL_REQUIRE(m && on_out, "tl_model_tp_peer_enabled: null argument");
+  *on_out = m->peer_on ? 1 : 0;
+  return 0;
+}

@@ -164,7 +164,8 @@ def tensor_kind(name):
     return KINDS[kn], int(li)
 
 
-PROFILE_KIND_INDEX = {"qkv_gemv": 1, "attn_out_gemv": 4, "gate_up_gemv": 5, "down_gemv": 6, "lm_head_gemv": 7}
+PROFILE_KIND_INDEX = {"qkv_gemv": 1, "attn_out_gemv": 4, "gate_up_gemv": 5, "down_gemv": 6, "lm_head_gemv": 7,
+                      "tp_all_reduce": 9}
 
 
 class Model:
@@ -200,6 +201,30 @@ class Model:
         """Join the RCCL communicator of the group (unique_id: 128 bytes from tp_unique_id() on rank 0)."""
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         check(lib().tl_model_tp_init(self.h, buf), "tl_model_tp_init")
+
+    def tp_peer_export(self):
+        """This rank's 64-byte IPC handle of its peer-exchange receive area (tl_model_tp_peer_export)."""
+        buf = (C.c_ubyte * 64)()
+        check(lib().tl_model_tp_peer_export(self.h, buf), "tl_model_tp_peer_export")
+        return bytes(buf)
+
+    def tp_peer_import(self, handles):
+        """Map the areas of all ranks (handles: tp_size x 64 bytes in rank order) and run the collective self-check:
+        True when every value arrived here. The ranks must still agree (min over ranks) before tp_peer_enable()."""
+        raw = b"".join(bytes(h) for h in handles)
+        assert len(raw) == 64 * self.tp_size, "one 64-byte handle per rank"
+        buf = (C.c_ubyte * len(raw)).from_buffer_copy(raw)
+        ok = C.c_int(0)
+        check(lib().tl_model_tp_peer_import(self.h, buf, C.byref(ok)), "tl_model_tp_peer_import")
+        return bool(ok.value)
+
+    def tp_peer_enable(self, on=True):
+        check(lib().tl_model_tp_peer_enable(self.h, int(bool(on))), "tl_model_tp_peer_enable")
+
+    def tp_peer_enabled(self):
+        out = C.c_int(0)
+        check(lib().tl_model_tp_peer_enabled(self.h, C.byref(out)), "tl_model_tp_peer_enabled")
+        return bool(out.value)
 
     def finalize(self):
         check(lib().tl_model_finalize(self.h), "tl_model_finalize")

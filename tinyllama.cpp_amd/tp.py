@@ -69,3 +69,60 @@ def local_dims(cfg, size):
     """Per-rank dimensions: query heads, kv heads, intermediate columns, vocab rows."""
     return dict(n_heads=cfg["n_heads"] // size, n_kv_heads=cfg["n_kv_heads"] // size, inter=cfg["inter"] // size,
                 vocab=cfg["vocab"] // size)
+
+
+# ---- wiring of the peer-to-peer exchange (csrc/tl_peer.hip) ---------------------------------------------------------------
+def peer_link(model, gather, agree):
+    """Link the shards of a group by the one-shot peer exchange, or leave them on the library collectives.
+
+    model: engine.Model of this rank (tp_size 2..8, not finalized). gather(b: bytes) -> [bytes of rank 0, 1, ...];
+    agree(flag: bool) -> logical AND of `flag` over all ranks. Both are collective calls of whatever channel the host
+    already has (torch.distributed in bench.py, files in the one-GPU test). Returns True when every rank passed the
+    self-check and the exchange was enabled on all of them; on False nothing changed (RCCL stays in charge)."""
+    handle, good = b"\0" * 64, True
+    try:
+        handle = model.tp_peer_export()
+    except Exception:
+        good = False
+    handles = gather(handle)
+    if not agree(good):
+        return False
+    try:
+        good = model.tp_peer_import(handles)
+    except Exception:
+        good = False
+    good = agree(good)
+    if good:
+        model.tp_peer_enable(True)
+    return good
+
+
+class FileRendezvous:
+    """gather / agree for peer_link over files in a directory shared by the ranks (processes of one host)."""
+
+    def __init__(self, directory, rank, world, timeout=120.0):
+        import os
+        self.dir, self.rank, self.world, self.timeout, self.seq = directory, rank, world, timeout, 0
+        os.makedirs(directory, exist_ok=True)
+
+    def gather(self, payload):
+        import os
+        import time
+        self.seq += 1
+        mine = os.path.join(self.dir, f"x{self.seq}_{self.rank}")
+        with open(mine + ".tmp", "wb") as f:
+            f.write(payload)
+        os.replace(mine + ".tmp", mine)  # atomic: a file that exists is complete
+        out, t0 = [], time.time()
+        for r in range(self.world):
+            path = os.path.join(self.dir, f"x{self.seq}_{r}")
+            while not os.path.exists(path):
+                if time.time() - t0 > self.timeout:
+                    raise TimeoutError(f"rank {r} did not show up at rendezvous step {self.seq}")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                out.append(f.read())
+        return out
+
+    def agree(self, flag):
+        return all(b == b"1" for b in self.gather(b"1" if flag else b"0"))

@@ -53,6 +53,12 @@ def parse():
     return ap.parse_args()
 
 
+# TL_BENCH_SHARE_GPU=1: all ranks of a `--gpus N` launch use GPU 0 (no RCCL communicator: it refuses two ranks on one
+# device; the shards are linked by the peer exchange only). A REHEARSAL of the control flow, not a measurement: the line
+# carries "rehearsal" and its numbers mean nothing.
+SHARE_GPU = os.environ.get("TL_BENCH_SHARE_GPU", "0") == "1"
+
+
 def dist_setup(n_gpus):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -61,8 +67,13 @@ def dist_setup(n_gpus):
     if world > 1:
         import torch
         import torch.distributed as dist_mod
-        torch.cuda.set_device(local)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if SHARE_GPU:  # rehearsal of the multi-rank path on a one-GPU box: every rank on device 0, gloo as the host channel
+            local = 0
+            torch.cuda.set_device(0)
+            dist_mod.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local))
         dist = dist_mod
     return rank, world, local, dist
 
@@ -107,7 +118,8 @@ def main():
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(engine.tp_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, src=0)
-            model.tp_init(uid.cpu().numpy().tobytes())
+            if not SHARE_GPU:
+                model.tp_init(uid.cpu().numpy().tobytes())
             # the decode step's 16 KB exchanges: one-shot peer-to-peer kernels over hipIpc-mapped areas (csrc/tl_peer.hip)
             # when every rank passes their self-check, else the RCCL calls (TL_TP_PEER=0 forces those)
             if os.environ.get("TL_TP_PEER", "1") != "0":
@@ -122,7 +134,10 @@ def main():
                     dist.all_reduce(t, op=dist.ReduceOp.MIN)
                     return bool(int(t.item()))
 
-                pkg_tp.peer_link(model, gather, agree)
+                linked = pkg_tp.peer_link(model, gather, agree)
+                if SHARE_GPU and not linked:
+                    raise RuntimeError("ranks sharing one GPU can only be linked by the peer exchange, which was refused: "
+                                       + engine.lib().tl_last_error().decode(errors="replace"))
         elif os.environ.get("TL_TP_SELFTEST"):  # one-rank communicator: the RCCL calls of the step on a single GPU
             model.tp_init(engine.tp_unique_id())
         for name, typ, rows, cols in plan:
@@ -248,6 +263,8 @@ def main():
         "eager_step_us": {k: round(v[0] * 1e3, 2) for k, v in prof.items()},
         "load_s": round(t_load, 1),
     }
+    if SHARE_GPU and world > 1:
+        out["rehearsal"] = f"{world} ranks share ONE GPU (TL_BENCH_SHARE_GPU=1): control-flow check only, the numbers are not a measurement"
 
     # ---- batched prefill on the matrix cores (outside the timed decode region): 512 prompt tokens, FP32-grade 6-term form
     # (under tensor parallelism every rank runs it: the prefill's all-reduces are collective calls)

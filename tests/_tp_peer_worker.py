@@ -26,6 +26,21 @@ def main():
         print(f"rank {rank}: peer link refused: {E.lib().tl_last_error().decode(errors='replace')}")
         return 3
     m.load(tensors)
+    if len(sys.argv) > 6 and sys.argv[6] == "rank1-absent":
+        # rank 1 stays linked and mapped but never steps: rank 0's exchange must give up at its deadline and the call
+        # must return an error (no hang), after which both ranks leave together
+        outcome = "n/a"
+        if rank == 0:
+            try:
+                m.decode(1, 0)
+                outcome = "no error"
+            except E.capi.TlError as e:
+                outcome = str(e)
+        rv.gather(outcome.encode())
+        np.savez(os.path.join(workdir, f"result_{rank}.npz"), linked=True, outcome=outcome)
+        rv.agree(True)
+        m.free()
+        return 0
     toks = np.random.default_rng(2).integers(0, cfg["vocab"], 9).astype(np.int32)
     logits = np.stack([m.decode(int(t), pos)[0] for pos, t in enumerate(toks)])
     nxt = int(np.argmax(logits[-1]))

@@ -61,3 +61,48 @@ def test_peer_linked_processes_match_oracle(pkg, oracle, tmp_path, shape, mix, t
         assert np.array_equal(r["logits"], res[0]["logits"]) and np.array_equal(r["ids"], res[0]["ids"])
         assert np.array_equal(r["last"], res[0]["last"])
     om.close()
+
+
+def _run_workers(tmp_path, tp, shape, mix, extra=(), env_extra=None):
+    env = dict(os.environ, TL_TP_PEER_TIMEOUT_MS="4000")
+    env.update(env_extra or {})
+    procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_tp_peer_worker.py"), str(r), str(tp), shape, mix,
+                               str(tmp_path), *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(tp)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=240)
+            outs.append(out.decode(errors="replace")[-2000:])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return procs, outs
+
+
+def test_missing_rank_is_an_error_not_a_hang(tmp_path):
+    """Rank 1 links but never steps: rank 0's decode gives up at the poll deadline and returns an error."""
+    procs, outs = _run_workers(tmp_path, 2, "tiny-gqa", "q4_k_m", extra=("rank1-absent",),
+                               env_extra={"TL_TP_PEER_TIMEOUT_MS": "300"})
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(outs)
+    r0 = dict(np.load(os.path.join(tmp_path, "result_0.npz")))
+    assert "timed out" in str(r0["outcome"]), r0["outcome"]
+
+
+def test_import_rejects_garbage_handles(pkg):
+    from tinyllama_cpp_amd import engine as E
+    from tinyllama_cpp_amd.capi import TlError
+    E.init(0)
+    cfg = dict(pkg.synth.SHAPES["tiny-gqa"])
+    m = E.Model(cfg, tp_rank=0, tp_size=2)
+    with pytest.raises(TlError):
+        m.tp_peer_import([b"\0" * 64, b"\0" * 64])  # nothing exported yet
+    handle = m.tp_peer_export()
+    assert len(handle) == 64
+    with pytest.raises(TlError):
+        m.tp_peer_import([handle, bytes(range(64))])  # rank 1's handle is not a handle
+    assert not m.tp_peer_enabled()
+    with pytest.raises(TlError):
+        E.Model(dict(pkg.synth.SHAPES["tiny"]), tp_rank=0, tp_size=1).tp_peer_export()  # tp_size 1 has nothing to link
+    m.free()

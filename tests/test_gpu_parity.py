@@ -85,7 +85,11 @@ def test_gemv_golden(E, golden, name):
 @pytest.mark.parametrize("name,rows,cols", [
     ("q4_k", 4096, 4096), ("q4_k", 1024, 14336), ("q4_k", 5632, 2048), ("q4_k", 333, 5632),
     ("q6_k", 1024, 4096), ("q6_k", 2048, 14336), ("q6_k", 3072, 3072), ("q8_0", 2048, 2048),
-    ("q8_0", 512, 5632), ("q8_0", 257, 32), ("q8_k", 768, 4096), ("q4_k", 1, 256), ("q6_k", 7, 28672)])
+    ("q8_0", 512, 5632), ("q8_0", 257, 32), ("q8_k", 768, 4096), ("q4_k", 1, 256), ("q6_k", 7, 28672),
+    # column counts that are not a multiple of the 2048-column span: the flattened step scheme (RA = 2 / 4), ragged rows
+    # (taken from 16 row groups per CU on; the small ones stay on the span scheme)
+    ("q4_k", 16390, 3072), ("q6_k", 16385, 3072), ("q8_0", 16387, 2304), ("q4_k", 16384, 5632), ("q8_k", 16388, 3072),
+    ("q4_k", 37, 3072), ("q6_k", 10, 11008), ("q8_0", 5, 2304), ("q4_k", 1, 5632)])
 def test_gemv_vs_oracle_model_shapes(E, pkg, oracle, name, rows, cols):
     """Shapes of the BASELINE configs (H x H, I x H, H x I, ragged row counts, one row, max K)."""
     t = TYPES[name]
@@ -315,6 +319,26 @@ def test_model_tinyllama_shape_two_layers(E, pkg, oracle):
     prompt = np.array([5, 1900, 77, 1024], np.int32)
     want_ids, want_logits = om.generate(prompt, 8, penalty=1.3, dump_logits=True)
     assert np.array_equal(m.generate(prompt, 8, penalty=1.3), want_ids)
+    m.reset_kv()
+    for pos, tok in enumerate(prompt):
+        logits, _ = m.decode(tok, pos)
+    assert close(logits, want_logits[0], LOGIT_TOL).all(), np.abs(logits - want_logits[0]).max()
+    m.free()
+    om.close()
+
+
+@pytest.mark.parametrize("mix", ["q6_k", "q4_k_m"])
+def test_model_llama32_3b_shape_two_layers(E, pkg, oracle, mix):
+    """Llama-3.2-3B's hidden size 3072 = 96 chunks per row: the projections that read the hidden vector run the
+    flattened step scheme of tl_gemv.hip where the launch is large enough for it (the gate/up pair, lm_head). 2 layers, cut
+    vocabulary: logits + greedy stream vs the oracle."""
+    cfg = dict(pkg.synth.SHAPES["llama-3.2-3b"], n_layers=2, vocab=16640, max_pos=64)
+    cfg, tensors = pkg.synth.build_model(cfg, mix, seed=13)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    prompt = np.array([9, 1500, 3, 700, 42], np.int32)
+    want_ids, want_logits = om.generate(prompt, 8, penalty=1.1, dump_logits=True)
+    assert np.array_equal(m.generate(prompt, 8, penalty=1.1), want_ids)
     m.reset_kv()
     for pos, tok in enumerate(prompt):
         logits, _ = m.decode(tok, pos)

@@ -531,10 +531,176 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   if (STAMP && ts[3] == 0) ts[3] = __builtin_readcyclecounter();
 }
 
+
+// ---- flattened steps: column counts that are not a multiple of the 2048-column span ---------------------------------
+// With cols = 3072 (Llama-3.2-3B) a row is 96 chunks: spans of 64 leave half the lanes of every second step idle
+// (25 % of the load slots); 5632 and 11008 columns waste 8 % and 10 %. Here a row group is RA consecutive rows per
+// weight stream (stream 0: rows ra .. ra+RA-1, stream 1: the same rows of the second matrix of a pair, or rows
+// ra+RA .. ra+2RA-1), and its RA * nchunks (row, chunk) items are dealt to the lanes as ONE sequence, 64 per step:
+// only the last step of a group can be partly empty (none at all when 64 divides RA * nchunks). Within a step the
+// lanes sit in at most two consecutive rows (nchunks > 64), so a lane's row is j0 or j0 + 1 and its chunk follows from
+// a running offset; the row is a per-lane value here (address arithmetic in VGPRs), which is why this is a variant
+// and not the default. Both streams still share one x chunk per lane. 2 * RA accumulators per lane.
+template <int TYPE, int RA>
+struct StepF {
+  Chunk<TYPE> c0, c1;
+  float r[2 * RA];  // residual values of the group's rows (RESID launches only)
+};
+struct StepMetaF {
+  int s, j0, off0, ra, rows;
+  float* out;
+};
+
+template <bool PAIR, int RPG>
+__device__ __forceinline__ void group_of_flat(const Segs& g, int rg, QW& wa, QW& wb, int& ra, float*& out) {
+  if (PAIR) {  // wa / wb / out were set once by the caller and never change
+    ra = rg * RPG;
+    return;
+  }
+  int seg = 0, lt = rg;
+  if (lt >= g.t0) { lt -= g.t0; seg = 1; }
+  if (seg == 1 && lt >= g.t1) { lt -= g.t1; seg = 2; }
+  const unsigned long long m0 = seg == 0 ? ~0ull : 0ull, m1 = seg == 1 ? ~0ull : 0ull, m2 = seg == 2 ? ~0ull : 0ull;
+  auto pick = [&](const void* x0, const void* x1, const void* x2) {
+    return reinterpret_cast<const uint8_t*>(((unsigned long long)x0 & m0) | ((unsigned long long)x1 & m1) |
+                                            ((unsigned long long)x2 & m2));
+  };
+  wa.p0 = pick(g.w0.p0, g.w1.p0, g.w2.p0);
+  wa.p1 = pick(g.w0.p1, g.w1.p1, g.w2.p1);
+  wa.p2 = pick(g.w0.p2, g.w1.p2, g.w2.p2);
+  wa.p3 = pick(g.w0.p3, g.w1.p3, g.w2.p3);
+  wa.rows = (int)(((unsigned)g.w0.rows & (unsigned)m0) | ((unsigned)g.w1.rows & (unsigned)m1) |
+                  ((unsigned)g.w2.rows & (unsigned)m2));
+  out = reinterpret_cast<float*>(const_cast<uint8_t*>(pick(g.o0, g.o1, g.o2)));
+  wb.p0 = wa.p0;
+  wb.p1 = wa.p1;
+  wb.p2 = wa.p2;
+  wb.p3 = wa.p3;
+  wb.rows = wa.rows;
+  ra = RPG * lt;
+}
+
+template <int TYPE, bool PAIR, bool RESID, bool XATTN, int RA>
+__device__ __forceinline__ void run_class_flat(const Segs& g, const GemvVec& a, const XRegs& xr, float* smem, int first,
+                                               int stride, int total, int lane) {
+  constexpr int RPG = PAIR ? RA : 2 * RA;  // output rows per group
+  const float* xs = smem + XS_SCRATCH;
+  const int nchunks = a.cols >> 5;                  // > 64 (host)
+  const int nsteps = (RA * nchunks + 63) >> 6;
+  if (first >= total) {
+    stage_x_finish<XATTN>(a, xr, smem);
+    return;
+  }
+  int irg = first, is = 0, ij0 = 0, ioff0 = 0;  // issue cursor: group, step, first row / chunk offset of the step
+  QW wa = g.w0, wb = PAIR ? g.w1 : g.w0;
+  int ra = 0;
+  float* out = g.o0;
+  group_of_flat<PAIR, RPG>(g, irg, wa, wb, ra, out);
+  float acc[2 * RA];
+#pragma unroll
+  for (int k = 0; k < 2 * RA; ++k) acc[k] = 0.f;
+
+  auto issue = [&](StepF<TYPE, RA>& st, StepMetaF& m) {
+    m.s = is;
+    m.j0 = ij0;
+    m.off0 = ioff0;
+    m.ra = ra;
+    m.rows = wa.rows;
+    m.out = out;
+    const int off = ioff0 + lane;
+    const bool hi = off >= nchunks;
+    int j = ij0 + (hi ? 1 : 0);
+    int chunk = hi ? off - nchunks : off;
+    if (j >= RA) {  // past the group's items (last step only): any valid address, contributes nothing
+      j = RA - 1;
+      chunk = nchunks - 1;
+    }
+    const int last = wa.rows - 1;
+    if (RESID) {
+#pragma unroll
+      for (int k = 0; k < 2 * RA; ++k) st.r[k] = ldg_f32(a.resid + (ra + k < last ? ra + k : last));
+    }
+    const int rowA = ra + j < last ? ra + j : last;
+    const int rowB = PAIR ? rowA : (ra + RA + j < last ? ra + RA + j : last);
+    st.c0.load(wa, rowA, (unsigned)chunk);
+    st.c1.load(wb, rowB, (unsigned)chunk);
+    ioff0 += 64;  // advance the issue cursor (scalar work, overlaps the loads)
+    if (ioff0 >= nchunks) {
+      ioff0 -= nchunks;
+      ++ij0;
+    }
+    if (++is == nsteps) {
+      is = 0;
+      ij0 = 0;
+      ioff0 = 0;
+      irg += stride;
+      if (irg < total) group_of_flat<PAIR, RPG>(g, irg, wa, wb, ra, out);
+    }
+  };
+  auto consume = [&](const StepF<TYPE, RA>& st, const StepMetaF& m) {
+    const int off = m.off0 + lane;
+    const bool hi = off >= nchunks;
+    const int j = m.j0 + (hi ? 1 : 0);
+    const int chunk = hi ? off - nchunks : off;
+    const bool act = j < RA;
+    const int cc = act ? chunk : nchunks - 1;
+    float x[32];
+    const f32x4* xp = reinterpret_cast<const f32x4*>(xs + cc * XS_STRIDE);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const f32x4 t = xp[i];
+      x[4 * i] = t[0]; x[4 * i + 1] = t[1]; x[4 * i + 2] = t[2]; x[4 * i + 3] = t[3];
+    }
+    const f32x4 sums = xp[8];
+    const float d0 = st.c0.dot(x, sums[0], sums[1], cc & 7);
+    const float d1 = st.c1.dot(x, sums[0], sums[1], cc & 7);
+#pragma unroll
+    for (int k = 0; k < RA; ++k) {
+      const bool hit = act && j == k;
+      acc[k] += hit ? d0 : 0.0f;
+      acc[RA + k] += hit ? d1 : 0.0f;
+    }
+    if (m.s == nsteps - 1) {  // row group complete: reduce, epilogue, store
+      float y[2 * RA];
+#pragma unroll
+      for (int k = 0; k < 2 * RA; ++k) {
+        y[k] = wave_sum_lane63(acc[k]);
+        acc[k] = 0.f;
+      }
+      if (lane == 63) {
+        if (PAIR) {
+#pragma unroll
+          for (int k = 0; k < RA; ++k) {
+            const float sg = 1.0f / (1.0f + expf(-y[k]));  // silu_cpu (utils.cpp:700-707), then * up (model.cpp:735)
+            if (m.ra + k < m.rows) stg_f32(m.out + m.ra + k, (y[k] * sg) * y[RA + k]);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 2 * RA; ++k)
+            if (m.ra + k < m.rows) stg_f32(m.out + m.ra + k, RESID ? st.r[k] + y[k] : y[k]);
+        }
+      }
+    }
+  };
+
+  StepF<TYPE, RA> cur, nxt;  // depth-one software pipeline in the copy form (see run_class)
+  StepMetaF mc, mn;
+  issue(cur, mc);
+  stage_x_finish<XATTN>(a, xr, smem);
+  while (irg < total) {
+    issue(nxt, mn);
+    consume(cur, mc);
+    cur = nxt;
+    mc = mn;
+  }
+  consume(cur, mc);
+}
+
 // TA: format of class A = segments [0, nsegA); TB: format of class B = segment nsegA (TL_NONE: no class B).
 // Waves [0, wavesA) of every workgroup run class A, the others class B.
 // ROLE only names the instantiation (tl_internal.h GemvRole) so that profiles separate the per-layer launches.
-template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
+// RA > 0: the flattened step scheme above with RA rows per stream and group (the host sizes t0..t2 accordingly).
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0>
 __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
                                                                 int t0, int t1, int t2, int nsegA, int wavesA) {
   // the roles launched with a residual / with x still in attention partials
@@ -565,14 +731,21 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
     const int wA = TB == TL_NONE ? nwaves : wavesA;
     const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
     const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, t0, nsegA >= 2 ? t1 : 0x3fffffff};
-    run_class<TA, PAIR, RESID, XATTN, STAMP>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane, ts);
+    if constexpr (RA > 0)
+      run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane);
+    else
+      run_class<TA, PAIR, RESID, XATTN, STAMP>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane, ts);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
     const int tb = nsegA == 1 ? t1 : t2;
     const Segs g = {sb.w, sb.w, sb.w, sb.out, sb.out, sb.out, 0x3fffffff, 0x3fffffff};
-    run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
-                                 gridDim.x * (nwaves - wavesA), tb, lane, ts);
+    if constexpr (RA > 0)
+      run_class_flat<TBB, false, false, XATTN, RA>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
+                                                   gridDim.x * (nwaves - wavesA), tb, lane);
+    else
+      run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
+                                                 gridDim.x * (nwaves - wavesA), tb, lane, ts);
   }
   if (STAMP && lane == 0 && ts[3] != 0) {
     ts[4] = __builtin_readcyclecounter();
@@ -623,19 +796,27 @@ struct Launch {
   int nsegA, wavesA;
   int grid, threads;
   size_t lds;
+  int ra;  // 0: span steps; 2 / 4: flattened steps with that many rows per stream and group
 };
 
-template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
-static int gemv_launch_one(const Launch& L, hipStream_t s) {
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0>
+static int gemv_launch_ra(const Launch& L, hipStream_t s) {
   static bool attr_done = false;
   if (!attr_done) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<TA, TB, PAIR, ROLE, STAMP>),
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_done = true;
   }
-  gemv_kernel<TA, TB, PAIR, ROLE, STAMP><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], L.v, L.t[0],
-                                                                           L.t[1], L.t[2], L.nsegA, L.wavesA);
+  gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], L.v, L.t[0],
+                                                                               L.t[1], L.t[2], L.nsegA, L.wavesA);
   return 0;
+}
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
+static int gemv_launch_one(const Launch& L, hipStream_t s) {
+  if constexpr (!STAMP && TA != TL_Q8_K) {  // (the host never picks the flattened scheme for Q8_K or the stamped run)
+    if (L.ra == 2) return gemv_launch_ra<TA, TB, PAIR, ROLE, false, 2>(L, s);
+  }
+  return gemv_launch_ra<TA, TB, PAIR, ROLE, STAMP, 0>(L, s);
 }
 
 template <int TA, int ROLE>
@@ -669,6 +850,32 @@ __global__ void swiglu_inplace_kernel(float* __restrict__ g, const float* __rest
   if (i >= n) return;
   const float x = g[i];
   g[i] = (x * (1.0f / (1.0f + expf(-x)))) * u[i];  // utils.cpp:704-705, model.cpp:735
+}
+
+// Step scheme of a launch: 0 = spans of 64 chunks; 2 = flattened steps with two rows per stream and group, when that
+// lowers the share of idle load slots AND the launch still has a row group for every wave of the chip: a flattened
+// group is twice the rows, and below 16 groups per CU the lost waves cost more than the idle slots (measured:
+// Llama-3.2-3B gate/up 14.2 -> 12.4 us and lm_head 71.8 -> 65.5 us, but attn_output 7.6 -> 8.1 us with 768 groups; four
+// rows per stream made TinyLlama's ffn_down, 256 groups, twice as slow). TL_GEMV_FLAT=0 switches it off for A/B runs.
+static int gemv_flat_rows(int cols, bool allowed, long total_rows, bool pair) {
+  static int enabled = -1;
+  if (enabled < 0) {
+    const char* e = getenv("TL_GEMV_FLAT");
+    enabled = e ? atoi(e) != 0 : 1;
+  }
+  const int nchunks = cols / 32;
+  if (!allowed || !enabled || nchunks <= 64 || nchunks % 64 == 0) return 0;
+  if (total_rows / (pair ? 2 : 4) < 16L * g_num_cus) return 0;
+  auto padded = [&](int ra) { return (double)((ra * nchunks + 63) / 64 * 64) / (double)(ra * nchunks); };
+  const double span = (double)((nchunks + 63) / 64 * 64) / (double)nchunks;
+  int best = 0;
+  double best_pad = span - 0.02;  // must save at least 2 % of the slots
+  for (int ra : {2})
+    if (padded(ra) < best_pad - 1e-9) {
+      best = ra;
+      best_pad = padded(ra);
+    }
+  return best;
 }
 
 static int gemv_geometry(Launch& L, int total) {
@@ -711,6 +918,11 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd};
   for (int i = 0; i < 3; ++i) L.seg[i] = a.seg[i < a.nseg ? i : 0];
   const int ta = a.seg[0].w.type;
+  bool flat_ok = true;
+  for (int i = 0; i < a.nseg; ++i) flat_ok &= a.seg[i].w.type != TL_Q8_K;
+  long total_rows = 0;
+  for (int i = 0; i < (a.pair ? 1 : a.nseg); ++i) total_rows += a.seg[i].w.rows;
+  L.ra = gemv_flat_rows(a.cols, flat_ok, total_rows, a.pair != 0);
 
   if (a.pair) {
     if (a.seg[1].w.type != ta) {
@@ -729,7 +941,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
       TL_HIP(hipGetLastError());
       return 0;
     }
-    L.t[0] = a.seg[0].w.rows;
+    L.t[0] = L.ra ? (a.seg[0].w.rows + L.ra - 1) / L.ra : a.seg[0].w.rows;
     L.nsegA = 2;
     gemv_geometry(L, L.t[0]);
     TL_TRY(gemv_launch_pair(ta, L, s));
@@ -754,7 +966,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   double bytesA = 0.0, bytesB = 0.0;
   int totalA = 0;
   for (int i = 0; i < a.nseg; ++i) {
-    L.t[i] = (a.seg[i].w.rows + 1) / 2;
+    L.t[i] = L.ra ? (a.seg[i].w.rows + 2 * L.ra - 1) / (2 * L.ra) : (a.seg[i].w.rows + 1) / 2;
     const double b = (double)a.seg[i].w.rows * a.cols / tl_type_block_elems(a.seg[i].w.type) *
                      (double)tl_type_block_bytes(a.seg[i].w.type);
     if (i < nsegA) {

@@ -211,6 +211,24 @@ int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* a
 int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out);
 /* algorithmic bytes one decode step at position pos must move on this rank (SURVEY §8d B_tok) */
 int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, double* kv_bytes);
+/* Multi-sequence decode (generate_batch api.cpp:836-1142; batch_prefill_parallel :1144, batch_generation_parallel :1423;
+ * forward_cpu_batch_generation model.cpp:1158-1523 / forward_device_batch_generation :1863-2114): up to max_batch
+ * sequences share the weights of every step -- the projections of the B tokens are skinny GEMMs on the matrix cores, the
+ * KV cache is sequence-major ([seq][max_pos][kv heads][head_dim], model.cpp:1310-1312), attention runs per token over its
+ * own sequence. tl_model_batch_init (after tl_model_finalize, tp_size 1) allocates that cache; tl_model_batch_prefill
+ * fills one sequence's prompt (positions start_pos..) and returns its last logits; tl_model_batch_decode is ONE step with
+ * batch_generation_parallel's arguments (token, position and sequence index per active sequence; indices must be
+ * distinct), returning logits [n][vocab] and/or the first-maximum ids; tl_model_batch_generate_greedy runs n_steps steps
+ * with ids and positions advancing on the device: out_ids_host [n_steps][n]. No repetition penalty on this path
+ * (api.cpp:993,1084). Each sequence decodes exactly as it would alone (the reference's sequential fallback,
+ * api.cpp:1116-1130); its parallel path leaves the current token out of its own attention (model.cpp:1327). */
+int tl_model_batch_init(tl_model* m, int max_batch);
+int tl_model_batch_prefill(tl_model* m, int seq_idx, const int* tokens_host, int num_tokens, int start_pos,
+                           float* last_logits_host);
+int tl_model_batch_decode(tl_model* m, int n, const int* tokens_host, const int* positions_host, const int* seq_idx_host,
+                          float* logits_host, int* next_tokens_host);
+int tl_model_batch_generate_greedy(tl_model* m, int n, const int* first_tokens_host, const int* start_pos_host,
+                                   const int* seq_idx_host, int n_steps, int* out_ids_host);
 /* tensor-parallel wiring (one process per GPU): RCCL communicator over xGMI; unique_id is the ncclUniqueId (128 bytes)
  * produced by tl_tp_unique_id on rank 0 and broadcast by the host (torch.distributed). Call tl_model_tp_init on every
  * rank before tl_model_finalize: the decode step (incl. its 2 all-reduces per layer and the logits all-gather) is

@@ -1,0 +1,108 @@
+"""Multi-sequence decode (generate_batch api.cpp:836, forward_cpu_batch_generation model.cpp:1158) on MI355X:
+B sequences with prompts of different lengths share every step's weight stream (skinny GEMMs on the matrix cores) over a
+sequence-major KV cache. The bar is the reference's sequential fallback: every sequence must decode exactly as it does
+alone -- logits within the decode tolerance of the single-sequence CPU oracle, identical greedy ids -- whatever else is
+in the batch, in whatever slot order, and while other sequences join or leave."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleModel
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4
+
+
+def close(a, b, tol):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
+
+
+def oracle_run(om, prompt, n_steps):
+    """greedy ids + the logits that produced each of them, single sequence, no penalty"""
+    om.reset_kv()
+    logits = None
+    for pos, t in enumerate(prompt):
+        _, logits = om.forward(om.lookup_embedding(int(t)), pos)
+    ids, rows = [], []
+    for i in range(n_steps):
+        rows.append(logits)
+        tok = int(np.argmax(logits))
+        ids.append(tok)
+        if i + 1 < n_steps:
+            _, logits = om.forward(om.lookup_embedding(tok), len(prompt) + i)
+    return np.array(ids, np.int32), np.stack(rows)
+
+
+@pytest.mark.parametrize("shape,mix", [("tiny-gqa", "q4_k_m"), ("tiny", "q6_k"), ("tiny-tp", "q8_0")])
+def test_batch_matches_single_sequence_oracle(pkg, oracle, shape, mix):
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model(shape, mix, seed=21)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    rng = np.random.default_rng(4)
+    lens = [5, 1, 17, 9, 3]
+    prompts = [rng.integers(0, cfg["vocab"], n).astype(np.int32) for n in lens]
+    slots = [3, 0, 6, 2, 5]  # sequence i lives in cache slot slots[i] (not the batch order)
+    n_steps = 7
+    want = [oracle_run(om, p, n_steps) for p in prompts]
+    m.batch_init(8)
+    # prompts: batched prefill per sequence into its slot; its last logits pick the first generated id
+    first = []
+    for p, s, (ids, rows) in zip(prompts, slots, want):
+        last = m.batch_prefill(s, p)
+        assert close(last, rows[0], LOGIT_TOL).all(), np.abs(last - rows[0]).max()
+        first.append(int(np.argmax(last)))
+        assert first[-1] == ids[0]
+    # step by step with logits: all five active, then sequences 1 and 3 leave (as finished ones do in the reference)
+    toks, pos = list(first), list(lens)
+    active = list(range(5))
+    for step in range(1, n_steps):
+        if step == 3:
+            active = [0, 2, 4]
+        logits, nxt = m.batch_decode([toks[i] for i in active], [pos[i] for i in active], [slots[i] for i in active])
+        for j, i in enumerate(active):
+            assert close(logits[j], want[i][1][step], LOGIT_TOL).all(), (step, i, np.abs(logits[j] - want[i][1][step]).max())
+            assert nxt[j] == want[i][0][step]
+            toks[i], pos[i] = int(nxt[j]), pos[i] + 1
+    # the device-resident loop from the same prompts (fresh prefill: the cache rows are simply overwritten)
+    for p, s in zip(prompts, slots):
+        m.batch_prefill(s, p)
+    ids = m.batch_generate_greedy(first, lens, slots, n_steps - 1)
+    for i in range(5):
+        assert np.array_equal(ids[:, i], want[i][0][1:]), i
+    # the single-sequence engine state is untouched by batch mode
+    single = m.generate(prompts[2], n_steps)
+    assert np.array_equal(single, want[2][0])
+    m.free()
+    om.close()
+
+
+def test_batch_argument_errors(pkg):
+    from tinyllama_cpp_amd import engine as E
+    from tinyllama_cpp_amd.capi import TlError
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model("tiny", "q4_k_m", seed=1)
+    m = E.Model(cfg).load(tensors)
+    with pytest.raises(TlError):
+        m.batch_decode([1], [0], [0])  # before batch_init
+    with pytest.raises(TlError):
+        m.batch_init(0)
+    with pytest.raises(TlError):
+        m.batch_init(100000)
+    m.batch_init(4)
+    with pytest.raises(TlError):
+        m.batch_prefill(4, [1, 2, 3])  # slot out of range
+    with pytest.raises(TlError):
+        m.batch_decode([1, 2], [0, 0], [1, 1])  # repeated sequence index
+    with pytest.raises(TlError):
+        m.batch_decode([1], [cfg["max_pos"]], [0])  # position out of range
+    with pytest.raises(TlError):
+        m.batch_decode([cfg["vocab"]], [0], [0])  # token id out of range
+    with pytest.raises(TlError):
+        m.batch_decode([1, 2, 3, 4, 5], [0] * 5, [0, 1, 2, 3, 4])  # more than max_batch (and slot 4)
+    with pytest.raises(TlError):
+        m.batch_generate_greedy([1], [cfg["max_pos"] - 2], [0], 5)  # would run past max_pos
+    m.free()
+    with pytest.raises(TlError):
+        E.Model(dict(pkg.synth.SHAPES["tiny-gqa"]), tp_rank=0, tp_size=2).batch_init(2)  # not finalized / sharded

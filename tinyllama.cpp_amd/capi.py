@@ -86,6 +86,10 @@ SIGNATURES = {
     "tl_tp_unique_id": [_vp],
     "tl_tp_local_group_prefill": [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
     "tl_model_graph_captured": [_vp, _vp],
+    "tl_model_batch_init": [_vp, C.c_int],
+    "tl_model_batch_prefill": [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
+    "tl_model_batch_decode": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
+    "tl_model_batch_generate_greedy": [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
     "tl_model_tp_init": [_vp, _vp],
     "tl_model_tp_peer_export": [_vp, _vp],
     "tl_model_tp_peer_import": [_vp, _vp, _vp],

@@ -1,0 +1,296 @@
+// tl_batch.hip — the position-dependent kernels of the MULTI-SEQUENCE decode step: B sequences advance one
+// token each per step; the projections run as skinny GEMMs on the matrix cores (tl_gemm.hip, the weights are read once
+// for all B tokens), and what depends on (sequence, position) lives here:
+//   - RoPE of q / k at each token's own position + K/V write into the SEQUENCE-MAJOR cache
+//     [seq][max_seq][n_kv_heads][head_dim] (forward_cpu_batch_generation, model.cpp:1302-1320: apply_rope_vector per
+//     token, kv_offset = (seq_idx * max_seq_len + pos) * kv_dim);
+//   - attention of every token over ITS sequence's cache rows 0..pos (model.cpp:1325-1382; the math is the
+//     single-sequence path's: scores scaled by 1/sqrt(hd), max-subtracted softmax, 1/(sum + 1e-9));
+//   - first-maximum arg-max of every token's logits row + the state advance of the device-resident generation loop
+//     (api.cpp:1069-1095; the reference applies no repetition penalty on this path, api.cpp:993,1084).
+// Semantics note: the reference's parallel path reads history_len = batch_seq_lens[seq] BEFORE that step's update
+// (model.cpp:1327, 1494-1496), i.e. a token does not attend to itself there, unlike in its own sequential fallback
+// (api.cpp:1116-1130 -> generate()). The target here is the sequential fallback: every sequence decodes exactly as it
+// would alone, which is also what the parity tests check against the single-sequence oracle.
+#include <math.h>
+
+#include <type_traits>
+
+#include "tl_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ float exp_diff(float m, float m_new) { return m == -INFINITY ? 0.f : expf(m - m_new); }
+
+// adjacent-pair rotation (utils.cpp:462-486), products rounded separately as on the host
+__device__ __forceinline__ void rot2(float a, float b, float c, float s, float& o0, float& o1) {
+#pragma clang fp contract(off)
+  o0 = __fsub_rn(__fmul_rn(a, c), __fmul_rn(b, s));
+  o1 = __fadd_rn(__fmul_rn(a, s), __fmul_rn(b, c));
+}
+
+// q [T][nq][hd], k [T][nkv][hd] rotated in place at pos[t]; k, v of token t written to cache row (seq[t], pos[t])
+__global__ void batch_rope_kv_kernel(float* __restrict__ q, float* __restrict__ k, const float* __restrict__ v,
+                                     float* __restrict__ kc, float* __restrict__ vc, size_t seq_stride,
+                                     const float* __restrict__ table, const int* __restrict__ pos,
+                                     const int* __restrict__ seq, int T, int nq, int nkv, int hd, int max_seq, int n_seq) {
+  const int half = hd >> 1, kv_dim = nkv * hd;
+  const int per_tok = (nq + nkv) * half + kv_dim;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)T * per_tok) return;
+  const int t = (int)(gid / per_tok), rem = (int)(gid % per_tok);
+  const int p = pos[t], sq = seq[t];
+  if (p < 0 || p >= max_seq || sq < 0 || sq >= n_seq) return;  // (validated on the host; never writes out of range)
+  const size_t row = (size_t)sq * seq_stride + (size_t)p * kv_dim;
+  if (rem < (nq + nkv) * half) {
+    const int h = rem / half, i = rem % half;
+    const float* tp = table + 2 * (size_t)p * half;
+    if (h < nq) {
+      float* x = q + ((size_t)t * nq + h) * hd;
+      float o0, o1;
+      rot2(x[2 * i], x[2 * i + 1], tp[2 * i], tp[2 * i + 1], o0, o1);
+      x[2 * i] = o0;
+      x[2 * i + 1] = o1;
+    } else {
+      float* x = k + ((size_t)t * nkv + (h - nq)) * hd;
+      float o0, o1;
+      rot2(x[2 * i], x[2 * i + 1], tp[2 * i], tp[2 * i + 1], o0, o1);
+      x[2 * i] = o0;
+      x[2 * i + 1] = o1;
+      float* dst = kc + row + (size_t)(h - nq) * hd;
+      dst[2 * i] = o0;
+      dst[2 * i + 1] = o1;
+    }
+  } else {
+    const int d = rem - (nq + nkv) * half;
+    vc[row + d] = v[(size_t)t * kv_dim + d];
+  }
+}
+
+struct BatchAttnArgs {
+  const float* q;   // [T][nh][hd], rotated
+  const float* kc;  // layer base of sequence 0: [n_seq][max_seq][nkv][hd]
+  const float* vc;
+  size_t seq_stride;
+  float* out;       // [T][nh][hd]
+  const int* pos;
+  const int* seq;
+  int nh, nkv, max_seq, n_seq;
+  float scale;
+};
+
+// One workgroup per (kv head, token, head-group part): the G query heads of the group share every K/V row read.
+// A K/V row is read by HD/4 lanes x 16 B; U rows of K and of V per lane are in flight together and folded into a
+// running (max, sum, out) per lane group (online softmax), then the lane groups and the waves are folded.
+template <int HD, int G>
+__global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a) {
+  constexpr int NW = 4, LP = HD / 4, PP = 64 / LP, U = 8, RECL = HD + 4;
+  __shared__ __attribute__((aligned(16))) float part[NW * G * RECL];
+  __shared__ float red[16];
+  const int kvh = blockIdx.x, tok = blockIdx.y;
+  const int head0 = (kvh * gridDim.z + blockIdx.z) * G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sub = lane / LP, ln = lane % LP;
+  const int pos = a.pos[tok], sq = a.seq[tok];
+  if (pos < 0 || pos >= a.max_seq || sq < 0 || sq >= a.n_seq) return;  // uniform
+  const int len = pos + 1;
+  const int kv_dim = a.nkv * HD;
+  const float* kbase = a.kc + (size_t)sq * a.seq_stride + (size_t)kvh * HD + 4 * ln;
+  const float* vbase = a.vc + (size_t)sq * a.seq_stride + (size_t)kvh * HD + 4 * ln;
+  f32x4 qf[G], acc[G];
+  float m[G], l[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    qf[g] = *reinterpret_cast<const f32x4*>(a.q + ((size_t)tok * a.nh + head0 + g) * HD + 4 * ln);
+    acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m[g] = -INFINITY;
+    l[g] = 0.f;
+  }
+  for (int base = 0; base < len; base += NW * PP * U) {
+    f32x4 kk[U], vv[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // unconditional, clamped loads: the whole batch in flight together
+      const int idx = base + (u * NW + wave) * PP + sub;
+      valid[u] = idx < len;
+      const size_t off = (size_t)(valid[u] ? idx : len - 1) * kv_dim;
+      kk[u] = *reinterpret_cast<const f32x4*>(kbase + off);
+      vv[u] = *reinterpret_cast<const f32x4*>(vbase + off);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      float s[U];
+      float mx = m[g];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float d = (qf[g][0] * kk[u][0] + qf[g][1] * kk[u][1]) + (qf[g][2] * kk[u][2] + qf[g][3] * kk[u][3]);
+#pragma unroll
+        for (int o = LP / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        s[u] = valid[u] ? d * a.scale : -INFINITY;
+        mx = fmaxf(mx, s[u]);
+      }
+      if (mx == -INFINITY) continue;  // nothing valid yet (uniform over the lane group)
+      const float corr = exp_diff(m[g], mx);
+      m[g] = mx;
+      l[g] *= corr;
+      acc[g][0] *= corr; acc[g][1] *= corr; acc[g][2] *= corr; acc[g][3] *= corr;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float p = valid[u] ? expf(s[u] - mx) : 0.f;
+        l[g] += p;
+        acc[g][0] = fmaf(p, vv[u][0], acc[g][0]);
+        acc[g][1] = fmaf(p, vv[u][1], acc[g][1]);
+        acc[g][2] = fmaf(p, vv[u][2], acc[g][2]);
+        acc[g][3] = fmaf(p, vv[u][3], acc[g][3]);
+      }
+    }
+  }
+  // fold the PP lane groups of a wave (shuffles), then the waves (LDS)
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+#pragma unroll
+    for (int o = 32; o >= LP; o >>= 1) {
+      const float mo = __shfl_xor(m[g], o);
+      const float mn = fmaxf(m[g], mo);
+      const float c = exp_diff(m[g], mn), co = exp_diff(mo, mn);
+      l[g] = l[g] * c + __shfl_xor(l[g], o) * co;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[g][e] = acc[g][e] * c + __shfl_xor(acc[g][e], o) * co;
+      m[g] = mn;
+    }
+    if (sub == 0) {
+      float* rec = part + (size_t)(wave * G + g) * RECL;
+      *reinterpret_cast<f32x4*>(rec + 4 * ln) = acc[g];
+      if (ln == 0) {
+        rec[HD] = m[g];
+        rec[HD + 1] = l[g];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    float M = -INFINITY;
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, part[(size_t)(w * G + tid) * RECL + HD]);
+    float L = 0.f;
+    for (int w = 0; w < NW; ++w) {
+      const float* rec = part + (size_t)(w * G + tid) * RECL;
+      L += rec[HD + 1] * exp_diff(rec[HD], M);
+    }
+    red[tid] = M;
+    red[8 + tid] = 1.0f / (L + 1e-9f);  // utils.cpp:692
+  }
+  __syncthreads();
+  for (int i = tid; i < G * HD; i += 256) {
+    const int g = i / HD, d = i % HD;
+    const float M = red[g];
+    float o = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float* rec = part + (size_t)(w * G + g) * RECL;
+      o += rec[d] * exp_diff(rec[HD], M);
+    }
+    a.out[((size_t)tok * a.nh + head0 + g) * HD + d] = o * red[8 + g];
+  }
+}
+
+template <int HD>
+int launch_attn_h(const BatchAttnArgs& a, int T, hipStream_t s) {
+  const int grp = a.nh / a.nkv;
+  auto go = [&](auto g_c, int parts) {
+    constexpr int G = decltype(g_c)::value;
+    attn_batch_decode_kernel<HD, G><<<dim3(a.nkv, T, parts), 256, 0, s>>>(a);
+  };
+  switch (grp) {
+    case 1: go(std::integral_constant<int, 1>{}, 1); break;
+    case 2: go(std::integral_constant<int, 2>{}, 1); break;
+    case 3: go(std::integral_constant<int, 3>{}, 1); break;
+    case 4: go(std::integral_constant<int, 4>{}, 1); break;
+    case 8: go(std::integral_constant<int, 4>{}, 2); break;
+    default: tl_set_error("batched decode attention: %d query heads per kv head is not supported", grp); return 2;
+  }
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// first maximum of every logits row (lowest index on ties, api.cpp:79,135 / std::max_element) + state advance
+__global__ __launch_bounds__(1024) void batch_argmax_advance_kernel(const float* __restrict__ logits, int V,
+                                                                    int* __restrict__ tokens, int* __restrict__ pos,
+                                                                    int* __restrict__ ids_out) {
+  __shared__ float bv[16];
+  __shared__ int bi[16];
+  const int t = blockIdx.x;
+  const float* row = logits + (size_t)t * V;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int i = threadIdx.x; i < V; i += 1024) {
+    const float v = row[i];
+    if (v > best) {
+      best = v;
+      idx = i;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const float ov = __shfl_xor(best, o);
+    const int oi = __shfl_xor(idx, o);
+    if (ov > best || (ov == best && oi < idx)) {
+      best = ov;
+      idx = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    bv[threadIdx.x >> 6] = best;
+    bi[threadIdx.x >> 6] = idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) {
+        best = bv[w];
+        idx = bi[w];
+      }
+    if (idx == 0x7fffffff) idx = 0;  // a row of NaN / -inf only
+    if (ids_out) ids_out[t] = idx;
+    if (tokens) tokens[t] = idx;
+    if (pos) pos[t] += 1;
+  }
+}
+
+}  // namespace
+
+int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,
+                            const int* pos_dev, const int* seq_dev, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
+                            hipStream_t s) {
+  TL_REQUIRE(q && k && v && kc && vc && table && pos_dev && seq_dev && T > 0 && hd % 2 == 0, "batch rope/kv: bad argument");
+  const size_t n = (size_t)T * ((size_t)(nq + nkv) * (hd / 2) + (size_t)nkv * hd);
+  batch_rope_kv_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(q, k, v, kc, vc, seq_stride, table, pos_dev, seq_dev, T, nq,
+                                                                   nkv, hd, max_seq, n_seq);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+bool tl_batch_attn_supported(int nh, int nkv, int hd) {
+  if (nkv <= 0 || nh % nkv != 0) return false;
+  const int g = nh / nkv;
+  return (hd == 64 || hd == 128) && (g == 1 || g == 2 || g == 3 || g == 4 || g == 8);
+}
+
+int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_t seq_stride, float* out, const int* pos_dev,
+                         const int* seq_dev, int T, int nh, int nkv, int hd, int max_seq, int n_seq, float scale,
+                         hipStream_t s) {
+  TL_REQUIRE(tl_batch_attn_supported(nh, nkv, hd), "batched decode attention: unsupported head configuration %d/%d/%d", nh,
+             nkv, hd);
+  TL_REQUIRE(q && kc && vc && out && pos_dev && seq_dev && T > 0 && T <= 65535, "batched decode attention: bad argument");
+  BatchAttnArgs a = {q, kc, vc, seq_stride, out, pos_dev, seq_dev, nh, nkv, max_seq, n_seq, scale};
+  return hd == 64 ? launch_attn_h<64>(a, T, s) : launch_attn_h<128>(a, T, s);
+}
+
+int tl_launch_batch_argmax_advance(const float* logits, int T, int V, int* tokens_dev, int* pos_dev, int* ids_out_dev,
+                                   hipStream_t s) {
+  TL_REQUIRE(logits && T > 0 && V > 0, "batch argmax: bad argument");
+  batch_argmax_advance_kernel<<<T, 1024, 0, s>>>(logits, V, tokens_dev, pos_dev, ids_out_dev);
+  TL_HIP(hipGetLastError());
+  return 0;
+}

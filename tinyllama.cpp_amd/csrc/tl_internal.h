@@ -180,3 +180,14 @@ int tl_peer_all_reduce(TlPeer* p, const float* in, float* out, hipStream_t s);
 int tl_peer_all_gather(TlPeer* p, float* buf, hipStream_t s);
 int tl_peer_error_async(TlPeer* p, unsigned* flag_host, hipStream_t s);
 void tl_peer_destroy(TlPeer* p);
+
+// ---- tl_batch.hip: position-dependent kernels of the multi-sequence decode step (sequence-major KV cache) ------------
+int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,
+                            const int* pos_dev, const int* seq_dev, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
+                            hipStream_t s);
+bool tl_batch_attn_supported(int nh, int nkv, int hd);
+int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_t seq_stride, float* out, const int* pos_dev,
+                         const int* seq_dev, int T, int nh, int nkv, int hd, int max_seq, int n_seq, float scale,
+                         hipStream_t s);
+int tl_launch_batch_argmax_advance(const float* logits, int T, int V, int* tokens_dev, int* pos_dev, int* ids_out_dev,
+                                   hipStream_t s);

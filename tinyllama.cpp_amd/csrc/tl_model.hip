@@ -97,8 +97,26 @@ struct tl_model {
   } pf;
   int prefill_terms = 0;     // MFMAs per product in the prefill GEMMs (0: tl_gemm_set_terms' process-wide value)
   int prefill_min_batch = 8; // prompts shorter than this replay the decode graph token by token
-  float* kc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems; }
-  float* vc(int l) const { return kv_base + (size_t)l * 2 * kv_layer_elems + kv_layer_elems; }
+  // multi-sequence decode: a second, SEQUENCE-MAJOR cache [layer][K|V][seq][max_pos][kv_dim] and the
+  // device-resident per-sequence state of the batched generation loop (tl_model_batch_init)
+  struct Batch {
+    int max_batch = 0;
+    float* kv = nullptr;
+    int *toks = nullptr, *pos = nullptr, *seq = nullptr;  // [max_batch]
+    int* ids = nullptr;                                   // generated ids [step][n]
+    size_t ids_cap = 0;
+  } bt;
+  int alt_seq = -1;  // >= 0: kc() / vc() address this sequence's region of the batch cache (prompt prefill of a sequence)
+  float* kc(int l) const {
+    return alt_seq >= 0 ? bt.kv + (((size_t)l * 2) * bt.max_batch + alt_seq) * kv_layer_elems
+                        : kv_base + (size_t)l * 2 * kv_layer_elems;
+  }
+  float* vc(int l) const {
+    return alt_seq >= 0 ? bt.kv + (((size_t)l * 2 + 1) * bt.max_batch + alt_seq) * kv_layer_elems
+                        : kv_base + (size_t)l * 2 * kv_layer_elems + kv_layer_elems;
+  }
+  float* bkc(int l) const { return bt.kv + ((size_t)l * 2) * bt.max_batch * kv_layer_elems; }      // sequence 0 of layer l
+  float* bvc(int l) const { return bt.kv + ((size_t)l * 2 + 1) * bt.max_batch * kv_layer_elems; }
 };
 
 static int upload_f32(float** dst, const void* host, size_t n, hipStream_t s) {
@@ -186,6 +204,11 @@ extern "C" int tl_model_free(tl_model* m) {
   for (float* b : pbufs) hipFree(b);
   hipFree(m->pf.planes);
   hipFree(m->pf.toks);
+  hipFree(m->bt.kv);
+  hipFree(m->bt.toks);
+  hipFree(m->bt.pos);
+  hipFree(m->bt.seq);
+  hipFree(m->bt.ids);
   if (m->pf.fork) hipEventDestroy(m->pf.fork);
   if (m->pf.join) hipEventDestroy(m->pf.join);
   if (m->pf.side) hipStreamDestroy(m->pf.side);
@@ -1112,6 +1135,166 @@ extern "C" int tl_tp_local_group_prefill(tl_model* const* ms, int n, const int* 
   if (rc > 1) return rc;
   TL_REQUIRE(rc == 0, "tl_tp_local_group_prefill: a HIP call failed: %s", hipGetErrorString(hipGetLastError()));
   TL_HIP(e);
+  return 0;
+}
+
+
+// ---- multi-sequence decode (generate_batch api.cpp:836-1142, batch_generation_parallel :1423,
+//      forward_cpu_batch_generation model.cpp:1158-1523 / forward_device_batch_generation :1863-2114) -------------------
+// B sequences advance one token each per step. The projections of the B tokens run as skinny GEMMs on the matrix cores
+// (the batched-prefill kernels: the weights are streamed once per step for all sequences), RoPE / KV write / attention
+// work per token on its own sequence's region of a sequence-major cache (tl_batch.hip), all-token logits come from one
+// more GEMM, and a per-row arg-max writes the next token ids and advances the positions on the device, so that a greedy
+// generation loop needs no host round trip per step. Every sequence decodes exactly as it would alone (see tl_batch.hip
+// on the reference's history_len quirk). tp_size 1 only.
+static int batch_attn_half(tl_model* m, int l, int T, hipStream_t s) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  LayerW& L = m->layers[l];
+  const int H = c.hidden_size, hd = m->head_dim;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  const size_t ps = p.plane_stride;
+  const float scale = 1.0f / sqrtf((float)hd);
+  TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+  TL_HIP(hipEventRecord(p.fork, s));
+  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
+  TL_HIP(hipEventRecord(p.join, p.side));
+  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  TL_TRY(tl_launch_batch_rope_kv(p.qb, p.kb, p.vb, m->bkc(l), m->bvc(l), m->kv_layer_elems, m->rope, m->bt.pos, m->bt.seq, T,
+                                 m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s));
+  TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
+                              m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s));
+  TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+  return tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s);
+}
+
+// one step for the T tokens in bt.toks / bt.pos / bt.seq; ids_dev: [T] next ids (first maximum of each logits row);
+// advance: the ids become the next tokens and the positions move on (device-resident loop)
+static int batch_step(tl_model* m, int T, int* ids_dev, bool advance, float* logits_host) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  hipStream_t s = m->stream;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  TL_TRY(prefill_embed(m, m->bt.toks, T, s));
+  for (int l = 0; l < c.num_hidden_layers; ++l) {
+    TL_TRY(batch_attn_half(m, l, T, s));
+    TL_TRY(prefill_mlp_half(m, l, T, s));
+  }
+  TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, c.hidden_size, terms, c.rms_norm_eps, s));
+  TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
+  if (logits_host)
+    TL_HIP(hipMemcpyAsync(logits_host, p.logits_all, sizeof(float) * (size_t)T * c.vocab_size, hipMemcpyDeviceToHost, s));
+  return tl_launch_batch_argmax_advance(p.logits_all, T, c.vocab_size, advance ? m->bt.toks : nullptr,
+                                        advance ? m->bt.pos : nullptr, ids_dev, s);
+}
+
+extern "C" int tl_model_batch_init(tl_model* m, int max_batch) {
+  TL_REQUIRE(m && m->finalized, "tl_model_batch_init: model not finalized");
+  TL_REQUIRE(m->tp == 1, "tl_model_batch_init: multi-sequence decode is not available on tensor-parallel shards");
+  TL_REQUIRE(max_batch >= 1 && max_batch <= kPrefillChunk, "tl_model_batch_init: max_batch %d outside 1..%d", max_batch,
+             kPrefillChunk);
+  TL_REQUIRE(tl_batch_attn_supported(m->nh_l, m->nkv_l, m->head_dim),
+             "tl_model_batch_init: head configuration %d/%d/%d is not supported by the batched decode attention", m->nh_l,
+             m->nkv_l, m->head_dim);
+  TL_REQUIRE(max_batch <= (m->cfg.max_position_embeddings < kPrefillChunk ? m->cfg.max_position_embeddings : kPrefillChunk),
+             "tl_model_batch_init: max_batch %d exceeds the chunk capacity of this model", max_batch);
+  TL_HIP(hipStreamSynchronize(m->stream));
+  tl_model::Batch& b = m->bt;
+  if (b.kv) {
+    TL_HIP(hipFree(b.kv));
+    TL_HIP(hipFree(b.toks));
+    TL_HIP(hipFree(b.pos));
+    TL_HIP(hipFree(b.seq));
+    b = tl_model::Batch();
+  }
+  const size_t elems = 2 * (size_t)m->cfg.num_hidden_layers * max_batch * m->kv_layer_elems;
+  TL_HIP(hipMalloc(&b.kv, sizeof(float) * elems));
+  TL_HIP(hipMemsetAsync(b.kv, 0, sizeof(float) * elems, m->stream));
+  TL_HIP(hipMalloc(&b.toks, sizeof(int) * max_batch));
+  TL_HIP(hipMalloc(&b.pos, sizeof(int) * max_batch));
+  TL_HIP(hipMalloc(&b.seq, sizeof(int) * max_batch));
+  b.max_batch = max_batch;
+  TL_TRY(ensure_prefill_ws(m, true));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// the prompt of ONE sequence into its region of the batch cache (positions start_pos ..), batched on the matrix cores
+extern "C" int tl_model_batch_prefill(tl_model* m, int seq_idx, const int* tokens_host, int num_tokens, int start_pos,
+                                      float* last_logits_host) {
+  TL_REQUIRE(m && m->bt.max_batch > 0, "tl_model_batch_prefill: call tl_model_batch_init first");
+  TL_REQUIRE(seq_idx >= 0 && seq_idx < m->bt.max_batch, "tl_model_batch_prefill: sequence %d outside [0,%d)", seq_idx,
+             m->bt.max_batch);
+  TL_REQUIRE(tokens_host && num_tokens > 0 && start_pos >= 0 && start_pos + num_tokens <= m->cfg.max_position_embeddings,
+             "tl_model_batch_prefill: positions [%d,%d) exceed max_position_embeddings %d", start_pos, start_pos + num_tokens,
+             m->cfg.max_position_embeddings);
+  m->alt_seq = seq_idx;
+  const int rc = prefill_batched(m, tokens_host, num_tokens, start_pos, last_logits_host, nullptr);
+  m->alt_seq = -1;
+  return rc;
+}
+
+static int batch_upload(tl_model* m, const char* who, int n, const int* tokens, const int* positions, const int* seqs,
+                        int extra_steps) {
+  TL_REQUIRE(m && m->bt.max_batch > 0, "%s: call tl_model_batch_init first", who);
+  TL_REQUIRE(n >= 1 && n <= m->bt.max_batch && tokens && positions && seqs, "%s: %d active sequences (1..%d)", who, n,
+             m->bt.max_batch);
+  std::vector<char> seen(m->bt.max_batch, 0);
+  for (int i = 0; i < n; ++i) {
+    TL_REQUIRE(seqs[i] >= 0 && seqs[i] < m->bt.max_batch && !seen[seqs[i]], "%s: sequence index %d out of range or repeated",
+               who, seqs[i]);
+    seen[seqs[i]] = 1;
+    TL_REQUIRE(positions[i] >= 0 && positions[i] + extra_steps <= m->cfg.max_position_embeddings,
+               "%s: position %d (+%d steps) exceeds max_position_embeddings %d", who, positions[i], extra_steps,
+               m->cfg.max_position_embeddings);
+    TL_REQUIRE(tokens[i] >= 0 && tokens[i] < m->cfg.vocab_size, "%s: token id %d outside the vocabulary", who, tokens[i]);
+  }
+  hipStream_t s = m->stream;
+  TL_HIP(hipMemcpyAsync(m->bt.toks, tokens, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  TL_HIP(hipMemcpyAsync(m->bt.pos, positions, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  TL_HIP(hipMemcpyAsync(m->bt.seq, seqs, sizeof(int) * n, hipMemcpyHostToDevice, s));
+  TL_HIP(hipStreamSynchronize(s));  // the host arrays belong to the caller
+  return 0;
+}
+static int batch_ids(tl_model* m, size_t n) {
+  if (m->bt.ids_cap < n) {
+    if (m->bt.ids) TL_HIP(hipFree(m->bt.ids));
+    m->bt.ids = nullptr;
+    m->bt.ids_cap = 0;
+    TL_HIP(hipMalloc(&m->bt.ids, sizeof(int) * n));
+    m->bt.ids_cap = n;
+  }
+  return 0;
+}
+
+// one step: token i of sequence seq_idx[i] at position positions[i] (batch_generation_parallel's arguments);
+// logits_host [n][vocab] and next_tokens_host [n] (first maximum of each row) may be NULL
+extern "C" int tl_model_batch_decode(tl_model* m, int n, const int* tokens_host, const int* positions_host,
+                                     const int* seq_idx_host, float* logits_host, int* next_tokens_host) {
+  TL_TRY(batch_upload(m, "tl_model_batch_decode", n, tokens_host, positions_host, seq_idx_host, 1));
+  TL_TRY(batch_ids(m, (size_t)n));
+  TL_TRY(batch_step(m, n, m->bt.ids, false, logits_host));
+  if (next_tokens_host)
+    TL_HIP(hipMemcpyAsync(next_tokens_host, m->bt.ids, sizeof(int) * n, hipMemcpyDeviceToHost, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
+  return 0;
+}
+
+// n_steps greedy steps for n sequences without a host round trip per step: out_ids_host [n_steps][n], sequence i's
+// ids in column i (the caller cuts a column at its EOS; the reference drops finished sequences from the batch, which
+// changes nothing for the others: sequences never interact)
+extern "C" int tl_model_batch_generate_greedy(tl_model* m, int n, const int* first_tokens_host, const int* start_pos_host,
+                                              const int* seq_idx_host, int n_steps, int* out_ids_host) {
+  TL_REQUIRE(n_steps >= 0 && out_ids_host, "tl_model_batch_generate_greedy: bad argument");
+  TL_TRY(batch_upload(m, "tl_model_batch_generate_greedy", n, first_tokens_host, start_pos_host, seq_idx_host, n_steps));
+  if (n_steps == 0) return 0;
+  TL_TRY(batch_ids(m, (size_t)n * n_steps));
+  for (int i = 0; i < n_steps; ++i) TL_TRY(batch_step(m, n, m->bt.ids + (size_t)i * n, true, nullptr));
+  TL_HIP(hipMemcpyAsync(out_ids_host, m->bt.ids, sizeof(int) * (size_t)n * n_steps, hipMemcpyDeviceToHost, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));
   return 0;
 }
 

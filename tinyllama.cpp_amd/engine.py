@@ -202,6 +202,38 @@ class Model:
         buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
         check(lib().tl_model_tp_init(self.h, buf), "tl_model_tp_init")
 
+    # ---- multi-sequence decode -------------------------------------------------------------------------
+    def batch_init(self, max_batch):
+        check(lib().tl_model_batch_init(self.h, int(max_batch)), "tl_model_batch_init")
+
+    def batch_prefill(self, seq_idx, tokens, start_pos=0):
+        """Prompt of one sequence into its region of the sequence-major cache; returns its last logits."""
+        toks = np.ascontiguousarray(tokens, np.int32)
+        last = np.empty(self.cfg["vocab"], np.float32)
+        check(lib().tl_model_batch_prefill(self.h, int(seq_idx), toks.ctypes.data, toks.size, int(start_pos),
+                                           last.ctypes.data), "tl_model_batch_prefill")
+        return last
+
+    def batch_decode(self, tokens, positions, seq_idx, want_logits=True):
+        """One step for the active sequences: (logits [n, vocab] or None, first-maximum ids [n])."""
+        t, p, q = (np.ascontiguousarray(a, np.int32) for a in (tokens, positions, seq_idx))
+        assert t.size == p.size == q.size
+        logits = np.empty((t.size, self.cfg["vocab"]), np.float32) if want_logits else None
+        nxt = np.empty(t.size, np.int32)
+        check(lib().tl_model_batch_decode(self.h, t.size, t.ctypes.data, p.ctypes.data, q.ctypes.data,
+                                          logits.ctypes.data if want_logits else None, nxt.ctypes.data),
+              "tl_model_batch_decode")
+        return logits, nxt
+
+    def batch_generate_greedy(self, first_tokens, start_pos, seq_idx, n_steps):
+        """n_steps greedy steps for all given sequences on the device: ids [n_steps, n]."""
+        t, p, q = (np.ascontiguousarray(a, np.int32) for a in (first_tokens, start_pos, seq_idx))
+        assert t.size == p.size == q.size
+        out = np.zeros((max(n_steps, 1), t.size), np.int32)
+        check(lib().tl_model_batch_generate_greedy(self.h, t.size, t.ctypes.data, p.ctypes.data, q.ctypes.data,
+                                                   int(n_steps), out.ctypes.data), "tl_model_batch_generate_greedy")
+        return out[:n_steps]
+
     def tp_peer_export(self):
         """This rank's 64-byte IPC handle of its peer-exchange receive area (tl_model_tp_peer_export)."""
         buf = (C.c_ubyte * 64)()

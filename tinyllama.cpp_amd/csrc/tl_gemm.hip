@@ -27,6 +27,8 @@
 //     weight-row tiles of ONE token panel, so a panel's activation planes (<= 3 MB) stay in that XCD's L2.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "tl_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -282,8 +284,13 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
   if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
   const int nt = tile / mtiles, mt = tile - nt * mtiles;
   const int m0 = mt * BM, n0 = nt * GB_N;
-  const int nk = K / GB_K, last = nk - 1;
+  // K split: slice blockIdx.y of gridDim.y covers steps [kbase, kbase + nk) and writes its partial tile to slice
+  // blockIdx.y of y (then a [gridDim.y][T][M] workspace without residual; summed by ksplit_reduce_kernel)
+  const int nk_all = K / GB_K, kper = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kbase = (int)blockIdx.y * kper;
+  const int nk = nk_all - kbase < kper ? nk_all - kbase : kper, last = kbase + nk - 1;
   const int nk3 = (nk + 2) / 3 * 3;  // both roles run a multiple of three steps (the tail steps only meet at the barrier)
+  if (gridDim.y > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
   if (threadIdx.x >= 256) {
     // ---------------- producers (waves 4-7: with round-robin wave placement one per SIMD, next to one consumer) ----------
     const int tid = threadIdx.x - 256;
@@ -303,6 +310,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     // (staged now), (kk+2)%3 holds step kk+2, and the set that held step kk is refilled with step kk+3.
     Regs s0, s1, s2;
     auto fetch = [&](Regs& g, int kn) {
+      kn += kbase;
       kn = kn < last ? kn : last;  // clamped, unconditional: the waits stay counted
 #pragma unroll
       for (int j = 0; j < MI; ++j) g.rw[j] = load8<TYPE>(w, grow[j], kn, wq);
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
       }
     };
     auto stage = [&](const Regs& g, int buf, int kn) {
+      kn += kbase;
       kn = kn < last ? kn : last;
       __bf16* wb = lds + buf * BUF;
       __bf16* xb = wb + NP * WPL;
@@ -448,6 +457,48 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
 
 int planes_of_terms(int terms) { return terms == 1 ? 1 : terms == 3 ? 2 : 3; }
 
+// y[o] = (resid ? resid[o] : 0) + sum over the K slices, in slice order
+__global__ void ksplit_reduce_kernel(const float* __restrict__ part, int S, size_t n, const float* __restrict__ resid,
+                                     float* __restrict__ y) {
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  float acc = part[o];
+  for (int z = 1; z < S; ++z) acc += part[(size_t)z * n + o];
+  y[o] = resid ? resid[o] + acc : acc;
+}
+static bool ksplit_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("TL_GEMM_KSPLIT");  // 0: never split K (A/B runs)
+    on = e ? atoi(e) != 0 : 1;
+  }
+  return on != 0;
+}
+static int gemm_num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            ? prop.multiProcessorCount
+            : 256;
+  }
+  return n;
+}
+// the workspace of a stream's K-split GEMMs: launches of one stream are ordered, launches of different streams (q | k, v
+// and gate | up run side by side) must not share one; -1 when more than 8 streams have been seen
+static int ksplit_slot(hipStream_t s) {
+  static std::mutex mu;
+  static hipStream_t seen[8];
+  static int n = 0;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < n; ++i)
+    if (seen[i] == s) return TL_SCRATCH_GEMM_PART0 + i;
+  if (n == 8) return -1;
+  seen[n] = s;
+  return TL_SCRATCH_GEMM_PART0 + n++;
+}
+
 template <int TYPE, int NP, int NT, int BM>
 int launch_gemm_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
   const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + GB_N - 1) / GB_N;
@@ -473,7 +524,36 @@ int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
-  gemm_q_ws_kernel<TYPE, NP, NT, BM><<<dim3(mtiles * ntiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  // Skinny problems (few token panels: the multi-sequence decode step, short prompts) have fewer tiles than the chip has
+  // workgroup slots (2 per CU): split K over up to 8 slices so that every CU streams weights, partial tiles into a
+  // per-stream workspace, summed in slice order (deterministic) with the residual by one small kernel.
+  const int tiles = mtiles * ntiles, nk_all = w.cols / GB_K;
+  int S = 1;
+  if (ksplit_enabled() && tiles < 2 * gemm_num_cus()) {
+    S = (2 * gemm_num_cus() + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+    if (S > nk_all / 12) S = nk_all / 12;  // at least a dozen steps per slice
+    if (S < 1) S = 1;
+    const int kper = (nk_all + S - 1) / S;
+    S = (nk_all + kper - 1) / kper;  // no empty slice
+  }
+  float* part = nullptr;
+  if (S > 1) {
+    const int slot = ksplit_slot(s);
+    if (slot < 0) S = 1;
+    else {
+      void* p = nullptr;
+      TL_TRY(tl_scratch(slot, sizeof(float) * (size_t)S * T * w.rows, &p));
+      part = static_cast<float*>(p);
+    }
+  }
+  if (S == 1) {
+    gemm_q_ws_kernel<TYPE, NP, NT, BM><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+  } else {
+    gemm_q_ws_kernel<TYPE, NP, NT, BM><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, part, nullptr, T, mtiles, ntiles);
+    const size_t n = (size_t)T * w.rows;
+    ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
+  }
   TL_HIP(hipGetLastError());
   return 0;
 }

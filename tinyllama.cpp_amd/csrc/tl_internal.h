@@ -30,7 +30,14 @@ void tl_set_error(const char* fmt, ...);
   } while (0)
 
 // lazily grown per-(device, slot) workspace of the operator-level entry points (tl_runtime.hip)
-enum TlScratchSlot { TL_SCRATCH_ATTN = 0, TL_SCRATCH_GEMM_PLANES, TL_SCRATCH_SAMPLE_PROBS, TL_SCRATCH_SAMPLE_PARAMS };
+enum TlScratchSlot {
+  TL_SCRATCH_ATTN = 0,
+  TL_SCRATCH_GEMM_PLANES,
+  TL_SCRATCH_SAMPLE_PROBS,
+  TL_SCRATCH_SAMPLE_PARAMS,
+  TL_SCRATCH_GEMM_PART0,  // + 0..7: K-split partial tiles, one workspace per stream (tl_gemm.hip)
+  TL_SCRATCH_GEMM_PART7 = TL_SCRATCH_GEMM_PART0 + 7
+};
 int tl_scratch(int slot, size_t bytes, void** out);
 
 // ---- device layout of one quantized matrix -----------------------------------------------------------

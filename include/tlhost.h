@@ -40,6 +40,13 @@ int tlh_session_seed(tlh_session* s, uint32_t seed);
 /* generate(): writes up to out_cap generated ids (prompt excluded), *n_out = how many */
 int tlh_session_generate(tlh_session* s, const int* prompt_ids, int n_prompt, int steps, float temperature, int top_k,
                          float top_p, int* out_ids, int out_cap, int* n_out);
+/* TinyLlamaSession's max_batch_size constructor argument (api.h:39-46), settable after open; default 1 */
+int tlh_session_set_max_batch(tlh_session* s, int max_batch_size);
+/* generate_batch() (api.cpp:836-1142) on ids: prompt i = prompt_ids[offsets[i] .. offsets[i+1]) (offsets has n_prompts + 1
+ * entries); out_ids is [n_prompts][steps] (row i holds out_lens[i] generated ids). Errors as the reference throws them:
+ * empty prompt list, more prompts than max_batch_size. */
+int tlh_session_generate_batch(tlh_session* s, const int* prompt_ids, const int* offsets, int n_prompts, int steps,
+                               float temperature, int top_k, float top_p, int* out_ids, int* out_lens);
 /* load statistics: tensors uploaded, quantized bytes taken from the mapping, seconds for open() */
 int tlh_session_load_stats(const tlh_session* s, uint64_t* tensors, uint64_t* quantized_bytes, double* seconds);
 

@@ -53,6 +53,43 @@ def test_session_generate_matches_oracle(H, pkg, oracle, tmp_path, shape, mix):
     om.close()
 
 
+def test_session_generate_batch_matches_single_sequence_runs(H, pkg, oracle, tmp_path):
+    """TinyLlamaSession::generate_batch on ids (api.cpp:836): every prompt's ids equal the oracle's single-sequence
+    greedy run without penalty, cut at EOS; the reference's argument errors; sampled batches stay in range."""
+    from tinyllama_cpp_amd.hostapi import TlHostError as HostError
+    S = pkg.synth
+    cfg, tensors = S.build_model("tiny-gqa", "q4_k_m", seed=17)
+    path = S.write_gguf(str(tmp_path / "b.gguf"), cfg, tensors)
+    s = H.Session(path)
+    om = OracleModel(oracle, cfg, tensors)
+    rng = np.random.default_rng(8)
+    prompts = [rng.integers(0, cfg["vocab"], n).astype(np.int32) for n in (3, 11, 1, 35)]
+    with pytest.raises(HostError):
+        s.generate_batch(prompts, 8, temperature=0.0)  # max_batch_size is 1 by default (api.h:46)
+    s.set_max_batch(6)
+    with pytest.raises(HostError):
+        s.generate_batch([], 8)  # "Cannot process empty prompts vector" (api.cpp:844)
+    got = s.generate_batch(prompts, 9, temperature=0.0)
+    assert len(got) == len(prompts)
+    for p, g in zip(prompts, got):
+        want = om.generate(p, 9, penalty=1.0, eos_id=2)
+        want = want[0] if isinstance(want, tuple) else want
+        assert np.array_equal(g, want), (len(p), g, want)
+    # a second call reuses the batch cache; single-sequence generate still works beside it
+    again = s.generate_batch(prompts[:2], 5, temperature=0.0)
+    assert np.array_equal(again[0], got[0][:5]) and np.array_equal(again[1], got[1][:5])
+    s.set_repetition_penalty(1.0)
+    one = s.generate(prompts[1], 9, temperature=0.0)
+    assert np.array_equal(one, got[1])
+    s.seed(3)
+    sampled = s.generate_batch(prompts, 6, temperature=0.9, top_k=30, top_p=0.9)
+    for g in sampled:
+        assert 1 <= len(g) <= 6 and ((g >= 0) & (g < cfg["vocab"])).all()
+        assert len(g) == 6 or g[-1] == 2
+    s.close()
+    om.close()
+
+
 def test_session_rejects_unusable_files(H, pkg, tmp_path):
     S = pkg.synth
     cfg, tensors = S.build_model("tiny", "q4_k_m", seed=13)

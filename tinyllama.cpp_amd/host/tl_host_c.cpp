@@ -1,6 +1,7 @@
 // tl_host_c.cpp — extern "C" view of the C++ host layer (include/tlhost.h).
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 
 #include "tl_session.hpp"
@@ -145,6 +146,28 @@ int tlh_session_generate(tlh_session* s, const int* prompt, int n_prompt, int st
     const int n = (int)ids.size() < out_cap ? (int)ids.size() : out_cap;
     if (out_ids) memcpy(out_ids, ids.data(), sizeof(int) * (size_t)n);
     *n_out = n;
+  });
+}
+int tlh_session_set_max_batch(tlh_session* s, int max_batch_size) {
+  if (!s) return fail("tlh_session_set_max_batch: null handle");
+  return guarded([&] { s->s->set_max_batch_size(max_batch_size); });
+}
+int tlh_session_generate_batch(tlh_session* s, const int* prompt_ids, const int* offsets, int n_prompts, int steps,
+                               float temperature, int top_k, float top_p, int* out_ids, int* out_lens) {
+  if (!s || n_prompts < 0 || (n_prompts > 0 && (!prompt_ids || !offsets)) || !out_lens || (steps > 0 && !out_ids))
+    return fail("tlh_session_generate_batch: bad argument");
+  return guarded([&] {
+    std::vector<std::vector<int>> prompts((size_t)n_prompts);
+    for (int i = 0; i < n_prompts; ++i) {
+      if (offsets[i + 1] < offsets[i]) throw std::runtime_error("tlh_session_generate_batch: offsets must not decrease");
+      prompts[i].assign(prompt_ids + offsets[i], prompt_ids + offsets[i + 1]);
+    }
+    const std::vector<std::vector<int>> out = s->s->generate_batch(prompts, steps, temperature, top_k, top_p);
+    for (int i = 0; i < n_prompts; ++i) {
+      const int n = (int)out[i].size() < steps ? (int)out[i].size() : steps;
+      out_lens[i] = n;
+      if (n > 0) memcpy(out_ids + (size_t)i * steps, out[i].data(), sizeof(int) * (size_t)n);
+    }
   });
 }
 int tlh_session_load_stats(const tlh_session* s, uint64_t* tensors, uint64_t* qbytes, double* seconds) {

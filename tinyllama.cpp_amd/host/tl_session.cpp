@@ -78,7 +78,7 @@ ModelConfig config_from_gguf(const GGUFFile& f) {
   return c;
 }
 
-Session::Session(const std::string& model_path, int device, int max_context) {
+Session::Session(const std::string& model_path, int device, int max_context, int max_batch_size) {
   const auto t0 = std::chrono::steady_clock::now();
   GGUFFile file;
   file.open(model_path);
@@ -87,6 +87,8 @@ Session::Session(const std::string& model_path, int device, int max_context) {
       config_.intermediate_size <= 0)
     throw std::runtime_error("Session: " + model_path + " lacks the llama.* shape metadata");
   if (max_context > 0 && max_context < config_.max_position_embeddings) config_.max_position_embeddings = max_context;
+  if (max_batch_size < 1) throw std::runtime_error("Session: max_batch_size must be >= 1");
+  max_batch_size_ = max_batch_size;
   tl_check(tl_init(device), "tl_init");
   tl_model_config mc = {};
   mc.hidden_size = config_.hidden_size;
@@ -187,6 +189,86 @@ std::vector<int> Session::generate(const std::vector<int>& prompt, int steps, fl
     if (next == config_.eos_token_id) break;
   }
   return generated;
+}
+
+void Session::set_max_batch_size(int n) {
+  if (n < 1) throw std::runtime_error("Session: max_batch_size must be >= 1");
+  max_batch_size_ = n;
+}
+
+std::vector<std::vector<int>> Session::generate_batch(const std::vector<std::vector<int>>& prompts, int steps,
+                                                      float temperature, int top_k, float top_p) {
+  if (prompts.empty()) throw std::runtime_error("Cannot process empty prompts vector for batch generation.");  // api.cpp:844
+  if ((int)prompts.size() > max_batch_size_)
+    throw std::runtime_error("Batch size " + std::to_string(prompts.size()) + " exceeds maximum batch size " +
+                             std::to_string(max_batch_size_));  // api.cpp:848-851
+  const int B = (int)prompts.size(), max_pos = config_.max_position_embeddings, V = config_.vocab_size;
+  std::vector<std::vector<int>> out((size_t)B);
+  if (steps <= 0) return out;
+  int longest = 0;
+  for (const auto& p : prompts) {
+    if (p.empty()) throw std::runtime_error("Session::generate_batch: empty prompt (the reference substitutes BOS after tokenizing, api.cpp:912-915)");
+    if ((int)p.size() > max_pos) throw std::runtime_error("Session::generate_batch: prompt longer than the context");
+    longest = std::max(longest, (int)p.size());
+  }
+  if (batch_ready_ < max_batch_size_) {  // kv_cache_.initialize_batch (api.cpp:925): once, for the session's maximum
+    tl_check(tl_model_batch_init(model_, max_batch_size_), "tl_model_batch_init");
+    batch_ready_ = max_batch_size_;
+  }
+  const bool greedy = temperature < 0.05f;
+  // ---- phase 1: the prompts (batch_prefill_parallel, api.cpp:1144): sequence i lives in cache slot i -------------------
+  std::vector<float> logits((size_t)V);
+  std::vector<int> cur((size_t)B), pos((size_t)B), seq((size_t)B);
+  std::vector<char> done((size_t)B, 0);
+  for (int i = 0; i < B; ++i) {
+    tl_check(tl_model_batch_prefill(model_, i, prompts[i].data(), (int)prompts[i].size(), 0, logits.data()),
+             "tl_model_batch_prefill");
+    cur[i] = greedy ? (int)(std::max_element(logits.begin(), logits.end()) - logits.begin())
+                    : sample_top_k_top_p_temperature(logits, temperature, top_k, top_p, rng_);
+    out[i].push_back(cur[i]);
+    pos[i] = (int)prompts[i].size();
+    seq[i] = i;
+    done[i] = cur[i] == config_.eos_token_id;
+  }
+  // ---- phase 2: steps 1 .. steps-1 (api.cpp:1013-1103), bounded by the context ------------------------------------------
+  if (greedy) {  // ids and positions advance on the device; a column is cut at its EOS afterwards (sequences never interact)
+    const int n_more = std::min(steps - 1, max_pos - longest);
+    if (n_more <= 0) return out;
+    std::vector<int> ids((size_t)n_more * B);
+    tl_check(tl_model_batch_generate_greedy(model_, B, cur.data(), pos.data(), seq.data(), n_more, ids.data()),
+             "tl_model_batch_generate_greedy");
+    for (int i = 0; i < B; ++i)
+      for (int k = 0; k < n_more && !done[i]; ++k) {
+        const int id = ids[(size_t)k * B + i];
+        out[i].push_back(id);
+        if (id == config_.eos_token_id) done[i] = 1;
+      }
+    return out;
+  }
+  std::vector<float> step_logits;
+  for (int step = 1; step < steps; ++step) {
+    std::vector<int> at, ap, as;  // the active sequences of this step (api.cpp:1031-1046)
+    for (int i = 0; i < B; ++i)
+      if (!done[i] && pos[i] < max_pos) {
+        at.push_back(cur[i]);
+        ap.push_back(pos[i]);
+        as.push_back(i);
+      }
+    if (at.empty()) break;
+    step_logits.resize(at.size() * (size_t)V);
+    tl_check(tl_model_batch_decode(model_, (int)at.size(), at.data(), ap.data(), as.data(), step_logits.data(), nullptr),
+             "tl_model_batch_decode");
+    for (size_t a = 0; a < at.size(); ++a) {
+      const int i = as[a];
+      std::copy(step_logits.begin() + a * V, step_logits.begin() + (a + 1) * V, logits.begin());
+      const int next = sample_top_k_top_p_temperature(logits, temperature, top_k, top_p, rng_);
+      cur[i] = next;
+      out[i].push_back(next);
+      ++pos[i];
+      if (next == config_.eos_token_id) done[i] = 1;
+    }
+  }
+  return out;
 }
 
 // ---- sampling on the host (non-greedy path) ---------------------------------------------------------------------------

@@ -34,7 +34,8 @@ class Session {
  public:
   // model_path: a .gguf file. device: HIP device ordinal. max_context > 0 caps the KV cache length below the file's
   // context length. tp_rank / tp_size: tensor-parallel shard (the caller wires the communicator through model()).
-  explicit Session(const std::string& model_path, int device = 0, int max_context = 0);
+  // max_batch_size: most prompts one generate_batch() call may carry (api.h:39-46; 1 = single-sequence use only).
+  explicit Session(const std::string& model_path, int device = 0, int max_context = 0, int max_batch_size = 1);
   ~Session();
   Session(const Session&) = delete;
   Session& operator=(const Session&) = delete;
@@ -45,6 +46,16 @@ class Session {
   std::vector<int> generate(const std::vector<int>& prompt_ids, int steps = 128, float temperature = 0.1f, int top_k = 40,
                             float top_p = 0.9f);
 
+  // TinyLlamaSession::generate_batch on ids (api.cpp:836-1142): all prompts advance together, one step streams the
+  // weights once for all of them (tl_model_batch_*). Returns the generated ids per prompt (an EOS ends a sequence and
+  // is kept, api.cpp:1004,1092). No repetition penalty on this path (api.cpp:993,1084). Throws std::runtime_error on an
+  // empty prompt list or more prompts than max_batch_size (api.cpp:844-851). temperature < 0.05: the whole loop runs
+  // on the device; otherwise the logits of the active sequences come back every step and the host sampler draws.
+  std::vector<std::vector<int>> generate_batch(const std::vector<std::vector<int>>& prompts, int steps = 128,
+                                               float temperature = 0.1f, int top_k = 40, float top_p = 0.9f);
+
+  void set_max_batch_size(int n);
+  int get_max_batch_size() const { return max_batch_size_; }
   void set_repetition_penalty(float p) { repetition_penalty_ = p; }
   float get_repetition_penalty() const { return repetition_penalty_; }
   void seed(uint32_t s) { rng_.seed(s); }
@@ -57,6 +68,8 @@ class Session {
   tl_model* model_ = nullptr;
   std::mt19937 rng_{std::random_device{}()};
   float repetition_penalty_ = 1.3f;  // api.h:135
+  int max_batch_size_ = 1;           // api.h:142
+  int batch_ready_ = 0;              // sequences the device-side batch cache was sized for
   LoadStats stats_;
 };
 

@@ -30,6 +30,8 @@ SIGNATURES = {
     "tlh_session_set_repetition_penalty": [_vp, _f],
     "tlh_session_seed": [_vp, C.c_uint32],
     "tlh_session_generate": [_vp, _vp, _i, _i, _f, _i, _f, _vp, _i, _vp],
+    "tlh_session_set_max_batch": [_vp, _i],
+    "tlh_session_generate_batch": [_vp, _vp, _vp, _i, _i, _f, _i, _f, _vp, _vp],
     "tlh_session_load_stats": [_vp, _vp, _vp, _vp],
     "tlh_apply_repetition_penalty": [_vp, _i, _vp, _i, _f],
     "tlh_sampling_distribution": [_vp, _i, _f, _i, _f, _vp, _vp, _i, _vp],
@@ -134,6 +136,22 @@ class Session:
         check(lib().tlh_session_generate(self.h, p.ctypes.data, p.size, int(steps), float(temperature), int(top_k),
                                          float(top_p), out.ctypes.data, out.size, C.byref(n)), "tlh_session_generate")
         return out[: n.value]
+
+    def set_max_batch(self, n):
+        check(lib().tlh_session_set_max_batch(self.h, int(n)), "tlh_session_set_max_batch")
+
+    def generate_batch(self, prompts, steps=128, temperature=0.1, top_k=40, top_p=0.9):
+        """TinyLlamaSession::generate_batch on ids: list of generated-id arrays, one per prompt."""
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(p, np.int32) for p in prompts]) if len(prompts) else
+                                    np.zeros(0, np.int32), np.int32)
+        offs = np.zeros(len(prompts) + 1, np.int32)
+        offs[1:] = np.cumsum([len(p) for p in prompts])
+        out = np.zeros((max(len(prompts), 1), max(steps, 1)), np.int32)
+        lens = np.zeros(max(len(prompts), 1), np.int32)
+        check(lib().tlh_session_generate_batch(self.h, flat.ctypes.data if flat.size else None, offs.ctypes.data,
+                                               len(prompts), int(steps), float(temperature), int(top_k), float(top_p),
+                                               out.ctypes.data, lens.ctypes.data), "tlh_session_generate_batch")
+        return [out[i, : lens[i]].copy() for i in range(len(prompts))]
 
     def load_stats(self):
         a, b, c = C.c_uint64(), C.c_uint64(), C.c_double()

@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--mix", default=None)
     ap.add_argument("--max-pos", type=int, default=2048, help="KV-cache length allocated for the run")
     ap.add_argument("--no-prefill-leg", action="store_true")
+    ap.add_argument("--no-batch-leg", action="store_true")
+    ap.add_argument("--batch-seqs", type=int, default=128, help="sequences of the multi-sequence decode leg")
     ap.add_argument("--prompt-len", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2, help="layers in the CPU-baseline sample")
@@ -274,6 +276,14 @@ def main():
         except Exception as e:  # the decode numbers above stay valid
             out["prefill"] = {"error": str(e)[:300]}
 
+    # ---- multi-sequence decode (generate_batch's engine; outside the timed single-sequence region): B
+    # sequences share every step's weight stream (skinny GEMMs on the matrix cores), FP32-grade 6-term products
+    if tp_world == 1 and world == 1 and not args.no_batch_leg and cfg["max_pos"] >= 64:
+        try:
+            out["multi_sequence"] = batch_leg(model, cfg, args.batch_seqs)
+        except Exception as e:
+            out["multi_sequence"] = {"error": str(e)[:300]}
+
     # ---- CPU baseline: the oracle in the reference's structure on a bounded sample ------------------------------
     if want_cpu:
         out["cpu_baseline"] = cpu_baseline(cfg, keep, args.cpu_layers, w_bytes)
@@ -281,6 +291,23 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def batch_leg(model, cfg, B, plen=16, steps=16, terms=6):
+    """aggregate tokens/s of tl_model_batch_generate_greedy: B sequences (prompts of plen tokens), `steps` greedy steps"""
+    rng = np.random.default_rng(2)
+    model.batch_init(B)
+    model.set_prefill(terms=terms, min_batch=8)
+    first = [int(np.argmax(model.batch_prefill(s, rng.integers(0, cfg["vocab"], plen).astype(np.int32)))) for s in range(B)]
+    seqs, pos = list(range(B)), [plen] * B
+    model.batch_generate_greedy(first, pos, seqs, 2)  # warm-up (its cache rows are overwritten by the timed run)
+    t0 = time.perf_counter()
+    ids = model.batch_generate_greedy(first, pos, seqs, steps)
+    dt = time.perf_counter() - t0
+    assert ids.shape == (steps, B)
+    return {"sequences": B, "steps": steps, "mfma_terms": terms, "ms_per_step": round(dt / steps * 1e3, 3),
+            "tokens_per_s_aggregate": round(B * steps / dt, 1), "positions": f"{plen}..{plen + steps - 1}",
+            "note": "every step streams the weights once for all sequences; each sequence decodes as it would alone"}
 
 
 def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3, world=1):

@@ -4,11 +4,11 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/prof_bench gpurun_out/prof_pmc
-TL_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 > gpurun_out/prof_bench.json 2> gpurun_out/prof_bench.err || exit 1
+TL_NO_GRAPH=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_bench -- python3 bench.py --no-cpu-baseline --steps 64 --warmup 8 --batch-seqs 32 > gpurun_out/prof_bench.json 2> gpurun_out/prof_bench.err || exit 1
 cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) gpurun_out/prof_bench_kernel_stats.csv
 head -12 gpurun_out/prof_bench_kernel_stats.csv
 rm -rf gpurun_out/prof_bench
-TL_NO_GRAPH=1 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_pmc -- python3 bench.py --no-cpu-baseline --steps 8 --warmup 2 > gpurun_out/prof_pmc.json 2> gpurun_out/prof_pmc.err || exit 1
+TL_NO_GRAPH=1 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/prof_pmc -- python3 bench.py --no-cpu-baseline --no-batch-leg --steps 8 --warmup 2 > gpurun_out/prof_pmc.json 2> gpurun_out/prof_pmc.err || exit 1
 python3 - <<'PY'
 import csv, glob, json
 f = glob.glob("gpurun_out/prof_pmc/*/*counter_collection.csv")[0]

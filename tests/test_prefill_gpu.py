@@ -68,6 +68,28 @@ def test_gemm_vs_oracle(E, pkg, oracle, name, rows, cols, T):
     assert np.array_equal(y3[1], w.matvec(x[1]))
 
 
+@pytest.mark.parametrize("name,rows,cols,T", [
+    ("q4_k", 4096, 4096, 2), ("q4_k", 333, 1024, 3), ("q4_k", 1024, 14336, 5), ("q6_k", 257, 4096, 4),
+    ("q6_k", 64, 14336, 7), ("q8_0", 1000, 2048, 6), ("q8_0", 33, 32, 2), ("q8_k", 128, 768, 3), ("q4_k", 1, 256, 7)])
+def test_few_tokens_take_the_multi_vector_gemv(E, pkg, oracle, name, rows, cols, T):
+    """2..7 tokens: one pass over the weights for up to four tokens (gemv_nv_kernel; 14336 columns only stage two
+    vectors at a time; Q8_K falls back to one mat-vec per token). Every row is bit-identical to the single mat-vec
+    (same chunk dots, same lane order) and within the GEMV tolerance of the oracle."""
+    t, S = TYPES[name], pkg.synth
+    rng = np.random.default_rng(rows + cols + T)
+    blocks = S.random_blocks(t, rows * cols // S.BLOCK_ELEMS[t], rng, w_std=1.0 / np.sqrt(cols))
+    x = rng.standard_normal((T, cols)).astype(np.float32)
+    x[0] *= 1e-3
+    x[-1] *= 50.0
+    w = E.QWeight(t, blocks, rows, cols)
+    y = _matmul(E, w, x)
+    want = oracle.matmul_q_batch(t, blocks, x, T, rows, cols)
+    sc = np.array([1e-3] + [1.0] * (T - 2) + [50.0], np.float32)[:, None]
+    assert close(y / sc, want / sc, 1e-4).all(), np.abs(y / sc - want / sc).max()
+    for i in range(T):
+        assert np.array_equal(y[i], w.matvec(x[i])), i
+
+
 def test_gemm_edge_scales(E, pkg, oracle):
     """fp16 sub-normal / zero / negative super-scales inside an MFMA tile."""
     from tinyllama_cpp_amd.capi import lib, check

@@ -645,6 +645,16 @@ extern "C" int tl_gemm_set_terms(int terms) {
 extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev, int num_tokens, void* stream) {
   TL_REQUIRE(w && x_dev && y_dev && num_tokens >= 0, "tl_matmul_q: bad argument");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // 2..7 tokens: the multi-vector GEMV (one pass over the weights for up to four tokens, tl_gemv.hip)
+  if (num_tokens >= 2 && num_tokens < 8 && (w->type == TL_Q4_K || w->type == TL_Q6_K || w->type == TL_Q8_0) &&
+      w->cols % 32 == 0 && tl_gemv_nv_capacity(w->cols) >= 2) {
+    GemvArgs a = {};
+    a.seg[0] = {qw_view(w), y_dev};
+    a.nseg = 1;
+    a.cols = w->cols;
+    a.x = x_dev;
+    return tl_launch_gemv_nv(a, num_tokens, s);
+  }
   if (num_tokens < 8 || w->type == TL_F32) {
     for (int t = 0; t < num_tokens; ++t)
       TL_TRY(tl_matvec_q(w, x_dev + (size_t)t * w->cols, y_dev + (size_t)t * w->rows, stream));

@@ -1164,3 +1164,261 @@ extern "C" int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float*
   *avg_us_out = ms * 1e3f / iters;
   return 0;
 }
+
+// ---- multi-vector GEMV: a FEW input vectors against ONE pass over the weights --------------------------------------------
+// The multi-sequence decode step with 2..8 sequences (tl_model_batch_*): too few tokens for the matrix-core GEMM (whose
+// cost per step does not depend on the token count below 128), too many to stream the weights once per token. Same
+// layout, chunk loads, per-format dot and depth-one register pipeline as the kernel above; the chunk in registers is
+// multiplied with the staged chunk of EVERY vector (the unpack work is shared, one FMA chain per vector), 2 * NV
+// accumulators per lane. x is [nv][cols] (RMSNorm per vector fused into the staging when norm_w is given), outputs are
+// [nv][rows of the segment], the residual is [nv][rows]. One format per launch (the host splits mixed QKV launches).
+// LDS holds NV staged vectors: (64 + NV * cols/32 * 36) floats must fit 160 KiB (the host splits the vectors otherwise).
+struct NvVec {
+  const float* x;
+  const float* norm_w;
+  const float* resid;
+  float eps;
+  int cols, nv;
+};
+
+template <int NV>
+__device__ __forceinline__ void stage_x_nv(const NvVec& a, float* smem) {
+  float* xs = smem + XS_SCRATCH;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int n4 = a.cols >> 2, nchunks = a.cols >> 5;
+  const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w);
+  float nf[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) nf[v] = 1.0f;
+  if (a.norm_w) {
+    float ssq[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      ssq[v] = 0.f;
+      if (v < a.nv) {
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (size_t)v * a.cols);
+        for (int i = tid; i < n4; i += nthr) ssq[v] += ssq4(x4[i]);
+      }
+      ssq[v] = wave_sum_all(ssq[v]);
+      if ((tid & 63) == 0) smem[v * 16 + (tid >> 6)] = ssq[v];  // NV * 16 = 64 floats = XS_SCRATCH at most
+    }
+    __syncthreads();
+    const float e = a.eps < 1e-5f ? 1e-5f : a.eps;  // SAFE_MAX(eps, MIN_NORM_EPS)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float tot = 0.f;
+      for (int w = 0; w < (nthr >> 6); ++w) tot += smem[v * 16 + w];
+      nf[v] = 1.0f / sqrtf(tot / (float)a.cols + e);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x + (size_t)(v < a.nv ? v : 0) * a.cols);
+    float* xv = xs + (size_t)v * nchunks * XS_STRIDE;
+    for (int i = tid; i < n4; i += nthr) {  // n4 is a multiple of 8 and nthr of 64: quads are all-in or all-out
+      f32x4 t = x4[i];
+      if (a.norm_w) {
+        const f32x4 g = w4[i];
+        t[0] = t[0] * nf[v] * g[0]; t[1] = t[1] * nf[v] * g[1]; t[2] = t[2] * nf[v] * g[2]; t[3] = t[3] * nf[v] * g[3];
+      }
+      const int idx = i << 2;
+      float* dst = xv + (idx >> 5) * XS_STRIDE;
+      *reinterpret_cast<f32x4*>(dst + (idx & 31)) = t;
+      float s = (t[0] + t[1]) + (t[2] + t[3]);
+      s += __shfl_xor(s, 1);
+      s += __shfl_xor(s, 2);
+      if ((i & 3) == 0) dst[32 + ((i >> 2) & 1)] = s;
+    }
+  }
+  __syncthreads();
+}
+
+template <int TYPE, int NV>
+struct StepNv {
+  Chunk<TYPE> c0, c1;
+  float r[2 * NV];
+};
+
+// MODE 0: plain, up to three segments of one format; 1: gate/up pair + SwiGLU; 2: one segment + residual
+// (NV = 4 runs 8 waves per workgroup: 2 * 4 accumulators, the residuals and two chunk buffers need more than the 128
+// VGPRs a lane has at 16 waves)
+template <int TYPE, int NV, int MODE>
+__global__ __launch_bounds__(NV <= 2 ? GEMV_MAX_THREADS : GEMV_MAX_THREADS / 2) void gemv_nv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, NvVec a, int t0,
+                                                                   int t1, int t2, int nseg) {
+  constexpr bool PAIR = MODE == 1, RESID = MODE == 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  const float* xs = smem + XS_SCRATCH;
+  const int nchunks = a.cols >> 5;
+  const int nspans = (nchunks + 63) >> 6;
+  const int total = PAIR ? t0 : (nseg == 1 ? t0 : (nseg == 2 ? t0 + t1 : t0 + t1 + t2));
+  const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, t0, nseg >= 2 ? t1 : 0x3fffffff};
+  const int first = wave * gridDim.x + blockIdx.x, stride = gridDim.x * nwaves;
+  if (first >= total) {
+    stage_x_nv<NV>(a, smem);
+    return;
+  }
+  int irg = first, isp = 0;
+  QW wa = g.w0, wb = PAIR ? g.w1 : g.w0;
+  int ra = 0, rb = 0;
+  float* out = g.o0;
+  group_of<PAIR>(g, irg, wa, wb, ra, rb, out);
+  float acc[2 * NV];
+#pragma unroll
+  for (int k = 0; k < 2 * NV; ++k) acc[k] = 0.f;
+
+  auto issue = [&](StepNv<TYPE, NV>& st, StepMeta& m) {
+    m.sp = isp;
+    m.ra = ra;
+    m.rows = wa.rows;
+    m.out = out;
+    const int chunk = (isp << 6) + lane;
+    const unsigned cc = chunk < nchunks ? chunk : nchunks - 1;
+    if (RESID) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const size_t vo = (size_t)(v < a.nv ? v : 0) * wa.rows;
+        st.r[2 * v] = ldg_f32(a.resid + vo + ra);
+        st.r[2 * v + 1] = ldg_f32(a.resid + vo + rb);
+      }
+    }
+    st.c0.load(wa, ra, cc);
+    st.c1.load(wb, rb, cc);
+    if (++isp == nspans) {
+      isp = 0;
+      irg += stride;
+      if (irg < total) group_of<PAIR>(g, irg, wa, wb, ra, rb, out);
+    }
+  };
+  auto consume = [&](const StepNv<TYPE, NV>& st, const StepMeta& m) {
+    const int chunk = (m.sp << 6) + lane;
+    const bool act = chunk < nchunks;
+    const int cc = act ? chunk : nchunks - 1;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      float x[32];
+      const f32x4* xp = reinterpret_cast<const f32x4*>(xs + ((size_t)v * nchunks + cc) * XS_STRIDE);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 t = xp[i];
+        x[4 * i] = t[0]; x[4 * i + 1] = t[1]; x[4 * i + 2] = t[2]; x[4 * i + 3] = t[3];
+      }
+      const f32x4 sums = xp[8];
+      const float d0 = st.c0.dot(x, sums[0], sums[1], cc & 7);
+      const float d1 = st.c1.dot(x, sums[0], sums[1], cc & 7);
+      acc[2 * v] += act ? d0 : 0.0f;
+      acc[2 * v + 1] += act ? d1 : 0.0f;
+    }
+    if (m.sp == nspans - 1) {  // row group complete: reduce, epilogue, store
+      float y[2 * NV];
+#pragma unroll
+      for (int k = 0; k < 2 * NV; ++k) {
+        y[k] = wave_sum_lane63(acc[k]);
+        acc[k] = 0.f;
+      }
+      if (lane == 63) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          if (v >= a.nv) continue;
+          float* o = m.out + (size_t)v * m.rows;
+          if (PAIR) {
+            const float sg = 1.0f / (1.0f + expf(-y[2 * v]));  // silu_cpu (utils.cpp:700-707), then * up (model.cpp:735)
+            stg_f32(o + m.ra, (y[2 * v] * sg) * y[2 * v + 1]);
+          } else {
+            stg_f32(o + m.ra, RESID ? st.r[2 * v] + y[2 * v] : y[2 * v]);
+            if (m.ra + 1 < m.rows) stg_f32(o + m.ra + 1, RESID ? st.r[2 * v + 1] + y[2 * v + 1] : y[2 * v + 1]);
+          }
+        }
+      }
+    }
+  };
+
+  StepNv<TYPE, NV> cur, nxt;
+  StepMeta mc, mn;
+  issue(cur, mc);  // the first weight loads go out before x is staged
+  stage_x_nv<NV>(a, smem);
+  while (irg < total) {
+    issue(nxt, mn);
+    consume(cur, mc);
+    cur = nxt;
+    mc = mn;
+  }
+  consume(cur, mc);
+}
+
+template <int TYPE, int NV, int MODE>
+static int gemv_nv_launch_inst(const Launch& L, const NvVec& v, int nseg, hipStream_t s) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_nv_kernel<TYPE, NV, MODE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_done = true;
+  }
+  gemv_nv_kernel<TYPE, NV, MODE><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], v, L.t[0], L.t[1], L.t[2], nseg);
+  return 0;
+}
+template <int TYPE, int NV>
+static int gemv_nv_launch_mode(int mode, const Launch& L, const NvVec& v, int nseg, hipStream_t s) {
+  if (mode == 1) return gemv_nv_launch_inst<TYPE, NV, 1>(L, v, nseg, s);
+  if (mode == 2) return gemv_nv_launch_inst<TYPE, NV, 2>(L, v, nseg, s);
+  return gemv_nv_launch_inst<TYPE, NV, 0>(L, v, nseg, s);
+}
+template <int TYPE>
+static int gemv_nv_launch_nv(int nvt, int mode, const Launch& L, const NvVec& v, int nseg, hipStream_t s) {
+  if (nvt == 2) return gemv_nv_launch_mode<TYPE, 2>(mode, L, v, nseg, s);
+  return gemv_nv_launch_mode<TYPE, 4>(mode, L, v, nseg, s);
+}
+
+// most vectors one launch can stage for this column count (0: not even two)
+int tl_gemv_nv_capacity(int cols) {
+  const size_t per = sizeof(float) * (size_t)(cols / 32) * XS_STRIDE, avail = 160 * 1024 - sizeof(float) * XS_SCRATCH;
+  const int fit = (int)(avail / per);
+  return fit >= 4 ? 4 : (fit >= 2 ? 2 : 0);
+}
+
+// a: as for tl_launch_gemv, with x [nv][cols], resid [nv][rows], every segment's out [nv][rows of the segment];
+// segments of one launch must share one format (Q4_K / Q6_K / Q8_0); no attention-partials input.
+int tl_launch_gemv_nv(const GemvArgs& a, int nv, hipStream_t s) {
+  TL_TRY(gemv_setup());
+  TL_REQUIRE(nv >= 1 && a.nseg >= 1 && a.nseg <= 3 && a.cols > 0 && a.cols % 32 == 0 && !a.attn_ws, "gemv_nv: bad argument");
+  const int ta = a.seg[0].w.type;
+  TL_REQUIRE(ta == TL_Q4_K || ta == TL_Q6_K || ta == TL_Q8_0, "gemv_nv: weight type %d has no multi-vector kernel", ta);
+  for (int i = 0; i < a.nseg; ++i)
+    TL_REQUIRE(a.seg[i].w.type == ta && a.seg[i].w.cols == a.cols && a.seg[i].w.rows > 0 && a.seg[i].out,
+               "gemv_nv: segment %d does not match the launch", i);
+  TL_REQUIRE(!a.pair || (a.nseg == 2 && a.seg[0].w.rows == a.seg[1].w.rows), "gemv_nv: pair mode needs two equal-shaped matrices");
+  TL_REQUIRE(!a.resid || (a.nseg == 1 && !a.pair), "gemv_nv: residual epilogue needs a single matrix");
+  const int cap = tl_gemv_nv_capacity(a.cols);
+  TL_REQUIRE(cap >= 2, "gemv_nv: %d columns do not fit two staged vectors", a.cols);
+  const int mode = a.pair ? 1 : (a.resid ? 2 : 0);
+  for (int v0 = 0; v0 < nv; v0 += cap) {
+    const int n = nv - v0 < cap ? nv - v0 : cap;
+    const int nvt = n <= 2 ? 2 : 4;
+    Launch L = {};
+    L.lds = sizeof(float) * (XS_SCRATCH + (size_t)nvt * (a.cols / 32) * XS_STRIDE);
+    if (L.lds < sizeof(float) * (XS_SCRATCH + 128)) L.lds = sizeof(float) * (XS_SCRATCH + 128);
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+      const GemvSeg& sg = a.seg[i < a.nseg ? i : 0];
+      L.seg[i] = GemvSeg{sg.w, sg.out + (size_t)v0 * sg.w.rows};
+      L.t[i] = a.pair ? sg.w.rows : (sg.w.rows + 1) / 2;
+      if (i < a.nseg && !(a.pair && i > 0)) total += L.t[i];
+    }
+    gemv_geometry(L, total);
+    if (nvt > 2 && L.threads > GEMV_MAX_THREADS / 2) L.threads = GEMV_MAX_THREADS / 2;
+    const NvVec vec = {a.x + (size_t)v0 * a.cols, a.norm_w, a.resid ? a.resid + (size_t)v0 * a.seg[0].w.rows : nullptr,
+                       a.eps, a.cols, n};
+    int rc = 0;
+    switch (ta) {
+      case TL_Q4_K: rc = gemv_nv_launch_nv<TL_Q4_K>(nvt, mode, L, vec, a.nseg, s); break;
+      case TL_Q6_K: rc = gemv_nv_launch_nv<TL_Q6_K>(nvt, mode, L, vec, a.nseg, s); break;
+      default: rc = gemv_nv_launch_nv<TL_Q8_0>(nvt, mode, L, vec, a.nseg, s); break;
+    }
+    TL_TRY(rc);
+    TL_HIP(hipGetLastError());
+  }
+  return 0;
+}

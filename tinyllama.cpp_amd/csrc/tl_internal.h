@@ -198,3 +198,7 @@ int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_
                          hipStream_t s);
 int tl_launch_batch_argmax_advance(const float* logits, int T, int V, int* tokens_dev, int* pos_dev, int* ids_out_dev,
                                    hipStream_t s);
+
+// multi-vector GEMV (tl_gemv.hip): nv input vectors [nv][cols] against one pass over the weights; outputs [nv][rows]
+int tl_gemv_nv_capacity(int cols);
+int tl_launch_gemv_nv(const GemvArgs& a, int nv, hipStream_t s);

@@ -33,9 +33,13 @@ def oracle_run(om, prompt, n_steps):
     return np.array(ids, np.int32), np.stack(rows)
 
 
+@pytest.mark.parametrize("gemv_max", ["12", "0", "3"])
 @pytest.mark.parametrize("shape,mix", [("tiny-gqa", "q4_k_m"), ("tiny", "q6_k"), ("tiny-tp", "q8_0")])
-def test_batch_matches_single_sequence_oracle(pkg, oracle, shape, mix):
+def test_batch_matches_single_sequence_oracle(pkg, oracle, monkeypatch, shape, mix, gemv_max):
+    """gemv_max: steps with at most that many sequences use multi-vector GEMVs, larger ones matrix-core GEMMs
+    (12 = default: every step of this test on GEMVs; 0: all on GEMMs; 3: the test crosses between the two)."""
     from tinyllama_cpp_amd import engine as E
+    monkeypatch.setenv("TL_BATCH_GEMV_MAX", gemv_max)
     E.init(0)
     cfg, tensors = pkg.synth.build_model(shape, mix, seed=21)
     m = E.Model(cfg).load(tensors)

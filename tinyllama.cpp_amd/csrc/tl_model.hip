@@ -105,6 +105,7 @@ struct tl_model {
     int *toks = nullptr, *pos = nullptr, *seq = nullptr;  // [max_batch]
     int* ids = nullptr;                                   // generated ids [step][n]
     size_t ids_cap = 0;
+    int gemv_max = 0;  // steps with at most this many sequences take the multi-vector GEMV route (0: never)
   } bt;
   int alt_seq = -1;  // >= 0: kc() / vc() address this sequence's region of the batch cache (prompt prefill of a sequence)
   float* kc(int l) const {
@@ -1171,6 +1172,97 @@ static int batch_attn_half(tl_model* m, int l, int T, hipStream_t s) {
   return tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s);
 }
 
+// The same step for a FEW sequences (T <= batch_gemv_max, default 12): the projections as multi-vector GEMVs
+// (gemv_nv_kernel: one pass over the weights for up to four tokens, RMSNorm / residual / SwiGLU fused as in the
+// single-sequence step) instead of matrix-core GEMMs, whose cost per step does not fall below that of 128 tokens.
+static bool batch_gemv_ok(const tl_model* m) {
+  auto ok = [](const tl_qweight* w) { return w->type == TL_Q4_K || w->type == TL_Q6_K || w->type == TL_Q8_0; };
+  if (!ok(m->out) || tl_gemv_nv_capacity(m->cfg.hidden_size) < 2 || tl_gemv_nv_capacity(m->I_l) < 2 ||
+      tl_gemv_nv_capacity(m->qd_l) < 2)
+    return false;
+  for (const LayerW& L : m->layers)
+    for (int k = 0; k < 7; ++k)
+      if (!ok(L.q[k])) return false;
+  return true;
+}
+static int batch_step_gemv(tl_model* m, int T, hipStream_t s) {
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  const int hd = m->head_dim;
+  const float scale = 1.0f / sqrtf((float)hd);
+  TL_TRY(prefill_embed(m, m->bt.toks, T, s));
+  for (int l = 0; l < c.num_hidden_layers; ++l) {
+    LayerW& L = m->layers[l];
+    {  // RMSNorm + q / k / v (one launch per run of equal formats)
+      const GemvSeg segs[3] = {{qw_view(L.q[TL_T_ATTN_Q]), p.qb}, {qw_view(L.q[TL_T_ATTN_K]), p.kb}, {qw_view(L.q[TL_T_ATTN_V]), p.vb}};
+      for (int i = 0; i < 3;) {
+        int j = i + 1;
+        while (j < 3 && segs[j].w.type == segs[i].w.type) ++j;
+        GemvArgs a = {};
+        for (int k = i; k < j; ++k) a.seg[k - i] = segs[k];
+        a.nseg = j - i;
+        a.cols = c.hidden_size;
+        a.x = p.xb;
+        a.norm_w = L.attn_norm;
+        a.eps = c.rms_norm_eps;
+        TL_TRY(tl_launch_gemv_nv(a, T, s));
+        i = j;
+      }
+    }
+    TL_TRY(tl_launch_batch_rope_kv(p.qb, p.kb, p.vb, m->bkc(l), m->bvc(l), m->kv_layer_elems, m->rope, m->bt.pos, m->bt.seq, T,
+                                   m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s));
+    TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
+                                m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s));
+    {  // attn_output + residual
+      GemvArgs a = {};
+      a.seg[0] = {qw_view(L.q[TL_T_ATTN_OUTPUT]), p.xb};
+      a.nseg = 1;
+      a.cols = m->qd_l;
+      a.x = p.ab;
+      a.resid = p.xb;
+      TL_TRY(tl_launch_gemv_nv(a, T, s));
+    }
+    {  // RMSNorm + gate / up + SwiGLU
+      GemvArgs a = {};
+      a.cols = c.hidden_size;
+      a.x = p.xb;
+      a.norm_w = L.ffn_norm;
+      a.eps = c.rms_norm_eps;
+      if (L.q[TL_T_FFN_GATE]->type == L.q[TL_T_FFN_UP]->type) {
+        a.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), p.gb};
+        a.seg[1] = {qw_view(L.q[TL_T_FFN_UP]), p.ub};
+        a.nseg = 2;
+        a.pair = 1;
+        TL_TRY(tl_launch_gemv_nv(a, T, s));
+      } else {
+        a.nseg = 1;
+        a.seg[0] = {qw_view(L.q[TL_T_FFN_GATE]), p.gb};
+        TL_TRY(tl_launch_gemv_nv(a, T, s));
+        a.seg[0] = {qw_view(L.q[TL_T_FFN_UP]), p.ub};
+        TL_TRY(tl_launch_gemv_nv(a, T, s));
+        TL_TRY(tl_swiglu(p.gb, p.ub, p.gb, (size_t)T * m->I_l, 0, s));  // decode form, as the fused pair epilogue
+      }
+    }
+    {  // ffn_down + residual
+      GemvArgs a = {};
+      a.seg[0] = {qw_view(L.q[TL_T_FFN_DOWN]), p.xb};
+      a.nseg = 1;
+      a.cols = m->I_l;
+      a.x = p.gb;
+      a.resid = p.xb;
+      TL_TRY(tl_launch_gemv_nv(a, T, s));
+    }
+  }
+  GemvArgs f = {};  // final RMSNorm + lm_head for every token
+  f.seg[0] = {qw_view(m->out), p.logits_all};
+  f.nseg = 1;
+  f.cols = c.hidden_size;
+  f.x = p.xb;
+  f.norm_w = m->out_norm;
+  f.eps = c.rms_norm_eps;
+  return tl_launch_gemv_nv(f, T, s);
+}
+
 // one step for the T tokens in bt.toks / bt.pos / bt.seq; ids_dev: [T] next ids (first maximum of each logits row);
 // advance: the ids become the next tokens and the positions move on (device-resident loop)
 static int batch_step(tl_model* m, int T, int* ids_dev, bool advance, float* logits_host) {
@@ -1178,13 +1270,17 @@ static int batch_step(tl_model* m, int T, int* ids_dev, bool advance, float* log
   tl_model::Prefill& p = m->pf;
   hipStream_t s = m->stream;
   const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
-  TL_TRY(prefill_embed(m, m->bt.toks, T, s));
-  for (int l = 0; l < c.num_hidden_layers; ++l) {
-    TL_TRY(batch_attn_half(m, l, T, s));
-    TL_TRY(prefill_mlp_half(m, l, T, s));
+  if (T <= m->bt.gemv_max) {
+    TL_TRY(batch_step_gemv(m, T, s));
+  } else {
+    TL_TRY(prefill_embed(m, m->bt.toks, T, s));
+    for (int l = 0; l < c.num_hidden_layers; ++l) {
+      TL_TRY(batch_attn_half(m, l, T, s));
+      TL_TRY(prefill_mlp_half(m, l, T, s));
+    }
+    TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, c.hidden_size, terms, c.rms_norm_eps, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
   }
-  TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, c.hidden_size, terms, c.rms_norm_eps, s));
-  TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
   if (logits_host)
     TL_HIP(hipMemcpyAsync(logits_host, p.logits_all, sizeof(float) * (size_t)T * c.vocab_size, hipMemcpyDeviceToHost, s));
   return tl_launch_batch_argmax_advance(p.logits_all, T, c.vocab_size, advance ? m->bt.toks : nullptr,
@@ -1217,6 +1313,11 @@ extern "C" int tl_model_batch_init(tl_model* m, int max_batch) {
   TL_HIP(hipMalloc(&b.pos, sizeof(int) * max_batch));
   TL_HIP(hipMalloc(&b.seq, sizeof(int) * max_batch));
   b.max_batch = max_batch;
+  b.gemv_max = batch_gemv_ok(m) ? 12 : 0;  // three passes of four vectors still beat the 128-token GEMM step
+  if (const char* e = getenv("TL_BATCH_GEMV_MAX")) {  // A/B runs: 0 = always the matrix-core GEMMs
+    const int v = atoi(e);
+    if (v >= 0 && v <= 64 && b.gemv_max) b.gemv_max = v;
+  }
   TL_TRY(ensure_prefill_ws(m, true));
   TL_HIP(hipStreamSynchronize(m->stream));
   return 0;

@@ -486,17 +486,33 @@ static int gemm_num_cus() {
   return n;
 }
 // the workspace of a stream's K-split GEMMs: launches of one stream are ordered, launches of different streams (q | k, v
-// and gate | up run side by side) must not share one; -1 when more than 8 streams have been seen
+// and gate | up run side by side) must not share one. Eight slots; a ninth stream takes over the slot used longest
+// ago after a device-wide sync (streams of freed models leave their slots behind); -1 only if that sync fails.
 static int ksplit_slot(hipStream_t s) {
   static std::mutex mu;
   static hipStream_t seen[8];
+  static unsigned long long used[8];
+  static unsigned long long tick = 0;
   static int n = 0;
   std::lock_guard<std::mutex> lock(mu);
+  ++tick;
   for (int i = 0; i < n; ++i)
-    if (seen[i] == s) return TL_SCRATCH_GEMM_PART0 + i;
-  if (n == 8) return -1;
-  seen[n] = s;
-  return TL_SCRATCH_GEMM_PART0 + n++;
+    if (seen[i] == s) {
+      used[i] = tick;
+      return TL_SCRATCH_GEMM_PART0 + i;
+    }
+  int slot = n;
+  if (n == 8) {
+    slot = 0;
+    for (int i = 1; i < 8; ++i)
+      if (used[i] < used[slot]) slot = i;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+  } else {
+    ++n;
+  }
+  seen[slot] = s;
+  used[slot] = tick;
+  return TL_SCRATCH_GEMM_PART0 + slot;
 }
 
 template <int TYPE, int NP, int NT, int BM>

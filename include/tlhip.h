@@ -225,6 +225,13 @@ int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, d
 int tl_model_batch_init(tl_model* m, int max_batch);
 int tl_model_batch_prefill(tl_model* m, int seq_idx, const int* tokens_host, int num_tokens, int start_pos,
                            float* last_logits_host);
+/* batch_prefill_parallel (api.cpp:1144): the tokens of ALL prompts as one packed batch (token i of sequence seq_idx[i] at
+ * position positions[i]; the tokens of a sequence in position order), sequence-aware attention
+ * (cpu_attention.cpp:254-325), chunks of 512 tokens. last_rows[j] = index of a token whose logits [n_last][vocab] and
+ * first-maximum id are returned (the last token of each prompt); n_last <= max_batch; either output may be NULL. */
+int tl_model_batch_prefill_packed(tl_model* m, int n_tokens, const int* tokens_host, const int* positions_host,
+                                  const int* seq_idx_host, int n_last, const int* last_rows_host, float* last_logits_host,
+                                  int* last_ids_host);
 int tl_model_batch_decode(tl_model* m, int n, const int* tokens_host, const int* positions_host, const int* seq_idx_host,
                           float* logits_host, int* next_tokens_host);
 int tl_model_batch_generate_greedy(tl_model* m, int n, const int* first_tokens_host, const int* start_pos_host,

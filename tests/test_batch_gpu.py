@@ -82,6 +82,64 @@ def test_batch_matches_single_sequence_oracle(pkg, oracle, monkeypatch, shape, m
     om.close()
 
 
+@pytest.mark.parametrize("shape,mix,lens", [("tiny-gqa", "q4_k_m", [5, 1, 17, 9, 3]), ("tiny", "q6_k", [40, 2, 33]),
+                                            ("tiny-tp", "q4_k_m", [12] * 12 + [7] * 13)])
+def test_packed_prefill_of_all_prompts(pkg, oracle, shape, mix, lens):
+    """batch_prefill_parallel (api.cpp:1144): every prompt's tokens in ONE packed batch with sequence-aware attention; the
+    last-token logits equal the single-sequence oracle's, and decode continues from the caches it left. (The layers of
+    a 35..250-token batch take the GEMM route; the head runs on the n_last rows only: multi-vector GEMVs for <= 12 rows,
+    a GEMM for the 25 of the third case.)"""
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model(shape, mix, seed=31)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    rng = np.random.default_rng(sum(lens))
+    prompts = [rng.integers(0, cfg["vocab"], n).astype(np.int32) for n in lens]
+    B = len(prompts)
+    slots = list(rng.permutation(B + 2)[:B])
+    m.batch_init(B + 2)
+    logits, ids = m.batch_prefill_packed(prompts, slots)
+    n_steps = 4
+    want = [oracle_run(om, p, n_steps) for p in prompts]
+    for i in range(B):
+        assert close(logits[i], want[i][1][0], LOGIT_TOL).all(), (i, np.abs(logits[i] - want[i][1][0]).max())
+        assert ids[i] == want[i][0][0]
+    out = m.batch_generate_greedy(ids, lens, slots, n_steps - 1)
+    for i in range(B):
+        assert np.array_equal(out[:, i], want[i][0][1:]), i
+    m.free()
+    om.close()
+
+
+def test_packed_prefill_rejects_bad_batches(pkg):
+    from tinyllama_cpp_amd import engine as E
+    from tinyllama_cpp_amd.capi import TlError, check, lib
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model("tiny", "q4_k_m", seed=1)
+    m = E.Model(cfg).load(tensors)
+    m.batch_init(2)
+
+    def call(toks, pos, seq, last):
+        a = [np.ascontiguousarray(x, np.int32) for x in (toks, pos, seq, last)]
+        ids = np.zeros(max(len(last), 1), np.int32)
+        check(lib().tl_model_batch_prefill_packed(m.h, a[0].size, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data,
+                                                  a[3].size, a[3].ctypes.data, None, ids.ctypes.data), "packed")
+        return ids
+    call([1, 2, 3], [0, 1, 0], [0, 0, 1], [1, 2])  # fine
+    with pytest.raises(TlError):
+        call([1, 2], [1, 0], [0, 0], [1])  # positions of a sequence out of order
+    with pytest.raises(TlError):
+        call([1, 2], [0, 0], [0, 2], [1])  # sequence index out of range
+    with pytest.raises(TlError):
+        call([1, 2], [0, 1], [0, 0], [2])  # output row outside the batch
+    with pytest.raises(TlError):
+        call([1, 2, 3], [0, 0, 1], [0, 1, 1], [0, 1, 2])  # more output rows than max_batch
+    with pytest.raises(TlError):
+        call([1, cfg["vocab"]], [0, 1], [0, 0], [1])  # token id
+    m.free()
+
+
 def test_batch_argument_errors(pkg):
     from tinyllama_cpp_amd import engine as E
     from tinyllama_cpp_amd.capi import TlError

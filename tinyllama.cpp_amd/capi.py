@@ -89,6 +89,7 @@ SIGNATURES = {
     "tl_model_batch_init": [_vp, C.c_int],
     "tl_model_batch_prefill": [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
     "tl_model_batch_decode": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp],
+    "tl_model_batch_prefill_packed": [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
     "tl_model_batch_generate_greedy": [_vp, C.c_int, _vp, _vp, _vp, C.c_int, _vp],
     "tl_model_tp_init": [_vp, _vp],
     "tl_model_tp_peer_export": [_vp, _vp],

@@ -103,6 +103,7 @@ struct tl_model {
     int max_batch = 0;
     float* kv = nullptr;
     int *toks = nullptr, *pos = nullptr, *seq = nullptr;  // [max_batch]
+    float* last_h = nullptr;                              // [max_batch][hidden]: hidden rows whose logits a packed prefill returns
     int* ids = nullptr;                                   // generated ids [step][n]
     size_t ids_cap = 0;
     int gemv_max = 0;  // steps with at most this many sequences take the multi-vector GEMV route (0: never)
@@ -210,6 +211,7 @@ extern "C" int tl_model_free(tl_model* m) {
   hipFree(m->bt.pos);
   hipFree(m->bt.seq);
   hipFree(m->bt.ids);
+  hipFree(m->bt.last_h);
   if (m->pf.fork) hipEventDestroy(m->pf.fork);
   if (m->pf.join) hipEventDestroy(m->pf.join);
   if (m->pf.side) hipStreamDestroy(m->pf.side);
@@ -1185,7 +1187,7 @@ static bool batch_gemv_ok(const tl_model* m) {
       if (!ok(L.q[k])) return false;
   return true;
 }
-static int batch_step_gemv(tl_model* m, int T, hipStream_t s) {
+static int batch_layers_gemv(tl_model* m, int T, hipStream_t s) {
   const tl_model_config& c = m->cfg;
   tl_model::Prefill& p = m->pf;
   const int hd = m->head_dim;
@@ -1253,34 +1255,48 @@ static int batch_step_gemv(tl_model* m, int T, hipStream_t s) {
       TL_TRY(tl_launch_gemv_nv(a, T, s));
     }
   }
-  GemvArgs f = {};  // final RMSNorm + lm_head for every token
-  f.seg[0] = {qw_view(m->out), p.logits_all};
-  f.nseg = 1;
-  f.cols = c.hidden_size;
-  f.x = p.xb;
-  f.norm_w = m->out_norm;
-  f.eps = c.rms_norm_eps;
-  return tl_launch_gemv_nv(f, T, s);
+  return 0;
 }
 
 // one step for the T tokens in bt.toks / bt.pos / bt.seq; ids_dev: [T] next ids (first maximum of each logits row);
 // advance: the ids become the next tokens and the positions move on (device-resident loop)
+// all layers for the T tokens in bt.toks / bt.pos / bt.seq: the residual stream ends up in pf.xb [T][hidden]
+static int batch_layers(tl_model* m, int T, hipStream_t s) {
+  TL_REQUIRE(T >= 1 && T <= m->pf.cap, "tl_model: a batched step of %d tokens exceeds the chunk workspaces (%d)", T, m->pf.cap);
+  if (T <= m->bt.gemv_max) return batch_layers_gemv(m, T, s);
+  TL_TRY(prefill_embed(m, m->bt.toks, T, s));
+  for (int l = 0; l < m->cfg.num_hidden_layers; ++l) {
+    TL_TRY(batch_attn_half(m, l, T, s));
+    TL_TRY(prefill_mlp_half(m, l, T, s));
+  }
+  return 0;
+}
+// final RMSNorm + lm_head of R hidden rows -> pf.logits_all [R][vocab]
+static int batch_head(tl_model* m, const float* hidden, int R, hipStream_t s) {
+  TL_REQUIRE(R >= 1 && R <= m->pf.cap, "tl_model: %d logits rows exceed the chunk workspaces (%d)", R, m->pf.cap);
+  const tl_model_config& c = m->cfg;
+  tl_model::Prefill& p = m->pf;
+  if (R <= m->bt.gemv_max) {
+    GemvArgs f = {};
+    f.seg[0] = {qw_view(m->out), p.logits_all};
+    f.nseg = 1;
+    f.cols = c.hidden_size;
+    f.x = hidden;
+    f.norm_w = m->out_norm;
+    f.eps = c.rms_norm_eps;
+    return tl_launch_gemv_nv(f, R, s);
+  }
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  TL_TRY(tl_launch_split(1, hidden, m->out_norm, p.planes, p.plane_stride, R, c.hidden_size, terms, c.rms_norm_eps, s));
+  return tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, R, terms, s);
+}
+
 static int batch_step(tl_model* m, int T, int* ids_dev, bool advance, float* logits_host) {
   const tl_model_config& c = m->cfg;
   tl_model::Prefill& p = m->pf;
   hipStream_t s = m->stream;
-  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
-  if (T <= m->bt.gemv_max) {
-    TL_TRY(batch_step_gemv(m, T, s));
-  } else {
-    TL_TRY(prefill_embed(m, m->bt.toks, T, s));
-    for (int l = 0; l < c.num_hidden_layers; ++l) {
-      TL_TRY(batch_attn_half(m, l, T, s));
-      TL_TRY(prefill_mlp_half(m, l, T, s));
-    }
-    TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, c.hidden_size, terms, c.rms_norm_eps, s));
-    TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
-  }
+  TL_TRY(batch_layers(m, T, s));
+  TL_TRY(batch_head(m, p.xb, T, s));
   if (logits_host)
     TL_HIP(hipMemcpyAsync(logits_host, p.logits_all, sizeof(float) * (size_t)T * c.vocab_size, hipMemcpyDeviceToHost, s));
   return tl_launch_batch_argmax_advance(p.logits_all, T, c.vocab_size, advance ? m->bt.toks : nullptr,
@@ -1304,14 +1320,17 @@ extern "C" int tl_model_batch_init(tl_model* m, int max_batch) {
     TL_HIP(hipFree(b.toks));
     TL_HIP(hipFree(b.pos));
     TL_HIP(hipFree(b.seq));
+    TL_HIP(hipFree(b.last_h));
+    if (b.ids) TL_HIP(hipFree(b.ids));
     b = tl_model::Batch();
   }
   const size_t elems = 2 * (size_t)m->cfg.num_hidden_layers * max_batch * m->kv_layer_elems;
   TL_HIP(hipMalloc(&b.kv, sizeof(float) * elems));
   TL_HIP(hipMemsetAsync(b.kv, 0, sizeof(float) * elems, m->stream));
-  TL_HIP(hipMalloc(&b.toks, sizeof(int) * max_batch));
-  TL_HIP(hipMalloc(&b.pos, sizeof(int) * max_batch));
-  TL_HIP(hipMalloc(&b.seq, sizeof(int) * max_batch));
+  TL_HIP(hipMalloc(&b.toks, sizeof(int) * kPrefillChunk));  // a packed prompt chunk carries up to kPrefillChunk tokens
+  TL_HIP(hipMalloc(&b.pos, sizeof(int) * kPrefillChunk));
+  TL_HIP(hipMalloc(&b.seq, sizeof(int) * kPrefillChunk));
+  TL_HIP(hipMalloc(&b.last_h, sizeof(float) * (size_t)max_batch * m->cfg.hidden_size));
   b.max_batch = max_batch;
   b.gemv_max = batch_gemv_ok(m) ? 12 : 0;  // three passes of four vectors still beat the 128-token GEMM step
   if (const char* e = getenv("TL_BATCH_GEMV_MAX")) {  // A/B runs: 0 = always the matrix-core GEMMs
@@ -1360,6 +1379,66 @@ static int batch_upload(tl_model* m, const char* who, int n, const int* tokens, 
   TL_HIP(hipStreamSynchronize(s));  // the host arrays belong to the caller
   return 0;
 }
+static int batch_ids(tl_model* m, size_t n);
+// batch_prefill_parallel (api.cpp:1144-1421): the tokens of ALL prompts in one packed batch, token i of sequence
+// seq_idx[i] at position positions[i]; attention is sequence-aware (attention_batch_cpu_sequence_aware,
+// cpu_attention.cpp:254-325): every K/V row of a chunk is written before its attention runs, and a token reads rows
+// 0..pos of its own sequence only. Tokens of one sequence must come in position order (as the reference packs them);
+// chunks of up to pf.cap (<= kPrefillChunk) tokens. last_rows[j]: index of a token whose logits / first-maximum id are wanted
+// (normally the last token of each prompt), at most max_batch of them.
+extern "C" int tl_model_batch_prefill_packed(tl_model* m, int n_tokens, const int* tokens_host, const int* positions_host,
+                                             const int* seq_idx_host, int n_last, const int* last_rows_host,
+                                             float* last_logits_host, int* last_ids_host) {
+  TL_REQUIRE(m && m->bt.max_batch > 0, "tl_model_batch_prefill_packed: call tl_model_batch_init first");
+  TL_REQUIRE(n_tokens >= 1 && tokens_host && positions_host && seq_idx_host, "tl_model_batch_prefill_packed: empty batch");
+  TL_REQUIRE(n_last >= 0 && n_last <= m->bt.max_batch && (n_last == 0 || last_rows_host),
+             "tl_model_batch_prefill_packed: %d output rows (at most max_batch = %d)", n_last, m->bt.max_batch);
+  const tl_model_config& c = m->cfg;
+  std::vector<int> next_pos(m->bt.max_batch, -1);  // position order within a sequence (first occurrence sets the start)
+  for (int i = 0; i < n_tokens; ++i) {
+    const int sq = seq_idx_host[i], ps = positions_host[i];
+    TL_REQUIRE(sq >= 0 && sq < m->bt.max_batch, "tl_model_batch_prefill_packed: sequence index %d outside [0,%d)", sq, m->bt.max_batch);
+    TL_REQUIRE(ps >= 0 && ps < c.max_position_embeddings, "tl_model_batch_prefill_packed: position %d outside [0,%d)", ps,
+               c.max_position_embeddings);
+    TL_REQUIRE(next_pos[sq] < 0 || ps == next_pos[sq],
+               "tl_model_batch_prefill_packed: the tokens of sequence %d are not in consecutive position order", sq);
+    next_pos[sq] = ps + 1;
+    TL_REQUIRE(tokens_host[i] >= 0 && tokens_host[i] < c.vocab_size, "tl_model_batch_prefill_packed: token id %d outside the vocabulary",
+               tokens_host[i]);
+  }
+  for (int j = 0; j < n_last; ++j)
+    TL_REQUIRE(last_rows_host[j] >= 0 && last_rows_host[j] < n_tokens, "tl_model_batch_prefill_packed: output row %d outside the batch",
+               last_rows_host[j]);
+  hipStream_t s = m->stream;
+  const size_t H = c.hidden_size;
+  const int chunk = m->pf.cap;  // tokens the chunk workspaces hold: min(kPrefillChunk, max_position_embeddings)
+  TL_REQUIRE(chunk >= 1 && chunk <= kPrefillChunk, "tl_model_batch_prefill_packed: workspaces are missing");
+  for (int c0 = 0; c0 < n_tokens; c0 += chunk) {
+    const int T = n_tokens - c0 < chunk ? n_tokens - c0 : chunk;
+    TL_HIP(hipMemcpyAsync(m->bt.toks, tokens_host + c0, sizeof(int) * T, hipMemcpyHostToDevice, s));
+    TL_HIP(hipMemcpyAsync(m->bt.pos, positions_host + c0, sizeof(int) * T, hipMemcpyHostToDevice, s));
+    TL_HIP(hipMemcpyAsync(m->bt.seq, seq_idx_host + c0, sizeof(int) * T, hipMemcpyHostToDevice, s));
+    TL_TRY(batch_layers(m, T, s));
+    for (int j = 0; j < n_last; ++j) {
+      const int r = last_rows_host[j] - c0;
+      if (r >= 0 && r < T)
+        TL_HIP(hipMemcpyAsync(m->bt.last_h + (size_t)j * H, m->pf.xb + (size_t)r * H, sizeof(float) * H, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  if (n_last > 0) {
+    TL_TRY(batch_ids(m, (size_t)n_last));
+    TL_TRY(batch_head(m, m->bt.last_h, n_last, s));
+    if (last_logits_host)
+      TL_HIP(hipMemcpyAsync(last_logits_host, m->pf.logits_all, sizeof(float) * (size_t)n_last * c.vocab_size,
+                            hipMemcpyDeviceToHost, s));
+    TL_TRY(tl_launch_batch_argmax_advance(m->pf.logits_all, n_last, c.vocab_size, nullptr, nullptr, m->bt.ids, s));
+    if (last_ids_host)
+      TL_HIP(hipMemcpyAsync(last_ids_host, m->bt.ids, sizeof(int) * n_last, hipMemcpyDeviceToHost, s));
+  }
+  TL_HIP(hipStreamSynchronize(s));  // also: the host arrays belong to the caller
+  return 0;
+}
+
 static int batch_ids(tl_model* m, size_t n) {
   if (m->bt.ids_cap < n) {
     if (m->bt.ids) TL_HIP(hipFree(m->bt.ids));

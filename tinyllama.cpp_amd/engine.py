@@ -214,6 +214,22 @@ class Model:
                                            last.ctypes.data), "tl_model_batch_prefill")
         return last
 
+    def batch_prefill_packed(self, prompts, slots=None, want_logits=True):
+        """All prompts as ONE packed batch (batch_prefill_parallel): prompt i into cache slot slots[i] (default i) from
+        position 0. Returns (last-token logits [n, vocab] or None, their first-maximum ids [n])."""
+        n = len(prompts)
+        slots = list(range(n)) if slots is None else [int(x) for x in slots]
+        toks = np.concatenate([np.asarray(p, np.int32) for p in prompts]).astype(np.int32)
+        pos = np.concatenate([np.arange(len(p), dtype=np.int32) for p in prompts])
+        seq = np.concatenate([np.full(len(p), s, np.int32) for p, s in zip(prompts, slots)])
+        last = (np.cumsum([len(p) for p in prompts]) - 1).astype(np.int32)
+        logits = np.empty((n, self.cfg["vocab"]), np.float32) if want_logits else None
+        ids = np.empty(n, np.int32)
+        check(lib().tl_model_batch_prefill_packed(self.h, toks.size, toks.ctypes.data, pos.ctypes.data, seq.ctypes.data, n,
+                                                  last.ctypes.data, logits.ctypes.data if want_logits else None,
+                                                  ids.ctypes.data), "tl_model_batch_prefill_packed")
+        return logits, ids
+
     def batch_decode(self, tokens, positions, seq_idx, want_logits=True):
         """One step for the active sequences: (logits [n, vocab] or None, first-maximum ids [n])."""
         t, p, q = (np.ascontiguousarray(a, np.int32) for a in (tokens, positions, seq_idx))

@@ -220,11 +220,27 @@ std::vector<std::vector<int>> Session::generate_batch(const std::vector<std::vec
   std::vector<float> logits((size_t)V);
   std::vector<int> cur((size_t)B), pos((size_t)B), seq((size_t)B);
   std::vector<char> done((size_t)B, 0);
+  {  // all prompts as one packed batch, token by token in sequence order (api.cpp:1175-1222)
+    std::vector<int> ptok, ppos, pseq, last((size_t)B);
+    for (int i = 0; i < B; ++i) {
+      for (size_t k = 0; k < prompts[i].size(); ++k) {
+        ptok.push_back(prompts[i][k]);
+        ppos.push_back((int)k);
+        pseq.push_back(i);
+      }
+      last[i] = (int)ptok.size() - 1;
+    }
+    std::vector<float> last_logits(greedy ? 0 : (size_t)B * V);
+    tl_check(tl_model_batch_prefill_packed(model_, (int)ptok.size(), ptok.data(), ppos.data(), pseq.data(), B, last.data(),
+                                           greedy ? nullptr : last_logits.data(), cur.data()),
+             "tl_model_batch_prefill_packed");
+    if (!greedy)
+      for (int i = 0; i < B; ++i) {
+        std::copy(last_logits.begin() + (size_t)i * V, last_logits.begin() + (size_t)(i + 1) * V, logits.begin());
+        cur[i] = sample_top_k_top_p_temperature(logits, temperature, top_k, top_p, rng_);
+      }
+  }
   for (int i = 0; i < B; ++i) {
-    tl_check(tl_model_batch_prefill(model_, i, prompts[i].data(), (int)prompts[i].size(), 0, logits.data()),
-             "tl_model_batch_prefill");
-    cur[i] = greedy ? (int)(std::max_element(logits.begin(), logits.end()) - logits.begin())
-                    : sample_top_k_top_p_temperature(logits, temperature, top_k, top_p, rng_);
     out[i].push_back(cur[i]);
     pos[i] = (int)prompts[i].size();
     seq[i] = i;

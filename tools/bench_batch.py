@@ -46,7 +46,9 @@ def main():
         prompts = [rng.integers(0, cfg["vocab"], a.prompt_len).astype(np.int32) for _ in range(B)]
         for terms in a.terms:
             m.set_prefill(terms=terms, min_batch=8)
-            first = [int(np.argmax(m.batch_prefill(s, p))) for s, p in enumerate(prompts)]
+            t0 = time.perf_counter()
+            _, first = m.batch_prefill_packed(prompts, want_logits=False)
+            t_prefill = time.perf_counter() - t0
             m.batch_generate_greedy(first, [a.prompt_len] * B, list(range(B)), 2)  # warm-up (rows are overwritten below)
             t0 = time.perf_counter()
             out = m.batch_generate_greedy(first, [a.prompt_len] * B, list(range(B)), a.steps)
@@ -56,6 +58,7 @@ def main():
                               "mfma_terms": terms, "steps": a.steps, "ms_per_step": round(dt / a.steps * 1e3, 3),
                               "tokens_per_s_aggregate": round(B * a.steps / dt, 1),
                               "single_sequence_tokens_per_s": round(single, 1),
+                              "packed_prefill_ms": round(t_prefill * 1e3, 2),
                               "positions": f"{a.prompt_len}..{a.prompt_len + a.steps - 1}"}), flush=True)
     m.free()
 

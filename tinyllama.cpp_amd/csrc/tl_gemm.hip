@@ -270,12 +270,16 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_q_kernel(QW w, const __bf16
 // rows x 128 tokens x 32 columns per step), same two swizzled LDS buffers, one workgroup barrier per step.
 constexpr int WS_THREADS = 512;
 
-template <int TYPE, int NP, int NT, int BM>
+// BN: tokens per tile, 128 or 64. At most 64 tokens (a multi-sequence decode step, a short prompt) would leave the
+// second token half of every 128-token tile empty: the 64-token form gives each consumer wave one 32-token fragment
+// instead of two and halves the activation staging.
+template <int TYPE, int NP, int NT, int BM, int BN>
 __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
                                                                float* __restrict__ y, const float* __restrict__ resid,
                                                                int T, int mtiles, int ntiles) {
   constexpr int MI = BM / 64;  // weight rows per producer thread; 32-row fragments per consumer wave
-  constexpr int WPL = BM * LROW, XPL = GB_N * LROW;
+  constexpr int NI = BN / 64;  // 64-token groups staged per producer thread; 32-token fragments per consumer wave
+  constexpr int WPL = BM * LROW, XPL = BN * LROW;
   constexpr int BUF = NP * (WPL + XPL);
   extern __shared__ __attribute__((aligned(16))) __bf16 lds[];
   const int M = w.rows, K = w.cols;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
   int tile = blockIdx.x;
   if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
   const int nt = tile / mtiles, mt = tile - nt * mtiles;
-  const int m0 = mt * BM, n0 = nt * GB_N;
+  const int m0 = mt * BM, n0 = nt * BN;
   // K split: slice blockIdx.y of gridDim.y covers steps [kbase, kbase + nk) and writes its partial tile to slice
   // blockIdx.y of y (then a [gridDim.y][T][M] workspace without residual; summed by ksplit_reduce_kernel)
   const int nk_all = K / GB_K, kper = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
@@ -298,12 +302,11 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     int grow[MI];
 #pragma unroll
     for (int j = 0; j < MI; ++j) grow[j] = m0 + wrow + 64 * j < M ? m0 + wrow + 64 * j : M - 1;
-    const int xr0 = tid >> 2, xr1 = xr0 + 64, xs = tid & 3;
+    const int xr0 = tid >> 2, xs = tid & 3;  // activation rows xr0 (+ 64): token n0 + xr0 (+ 64)
     const __bf16* xg0 = xp + (size_t)(n0 + xr0) * K + xs * 8;
-    const __bf16* xg1 = xp + (size_t)(n0 + xr1) * K + xs * 8;
     struct Regs {
       Raw8 rw[MI];
-      bf16x8 rx[NP][2];
+      bf16x8 rx[NP][NI];
     };
     // three register sets in rotation, the loop unrolled by three so that the rotation is register renaming and not
     // copying (a copy of a set with loads in flight would wait for them): at step kk the set (kk+1)%3 holds step kk+1
@@ -315,10 +318,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
 #pragma unroll
       for (int j = 0; j < MI; ++j) g.rw[j] = load8<TYPE>(w, grow[j], kn, wq);
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        g.rx[p][0] = *reinterpret_cast<const bf16x8*>(xg0 + p * plane_stride + (size_t)kn * GB_K);
-        g.rx[p][1] = *reinterpret_cast<const bf16x8*>(xg1 + p * plane_stride + (size_t)kn * GB_K);
-      }
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          g.rx[p][i] = *reinterpret_cast<const bf16x8*>(xg0 + (size_t)(64 * i) * K + p * plane_stride + (size_t)kn * GB_K);
     };
     auto stage = [&](const Regs& g, int buf, int kn) {
       kn += kbase;
@@ -335,10 +338,9 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
         for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x8*>(wb + p * WPL + lds_off(wrow + 64 * j, wq)) = wp[p];
       }
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0, xs)) = g.rx[p][0];
-        *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr1, xs)) = g.rx[p][1];
-      }
+      for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0 + 64 * i, xs)) = g.rx[p][i];
     };
     fetch(s0, 0);
     fetch(s1, 1);
@@ -358,13 +360,13 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     }
     return;
   }
-  // ---------------- consumers: wave = 64 tokens x BM/2 rows ----------------
+  // ---------------- consumers: wave = BN/2 tokens x BM/2 rows ----------------
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave & 1, wn = wave >> 1;
   const int fr = lane & 31, fh = lane >> 5;
-  f32x16 acc[2][MI];
+  f32x16 acc[NI][MI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < MI; ++j)
 #pragma unroll
@@ -379,11 +381,12 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     const __bf16* xb = wb + NP * WPL;
 #pragma unroll
     for (int k16 = 0; k16 < 2; ++k16) {
-      bf16x8 a[NP][2], b[NP][MI];
+      bf16x8 a[NP][NI], b[NP][MI];
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        a[p][0] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + fr, k16 * 2 + fh));
-        a[p][1] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 + fr, k16 * 2 + fh));
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          a[p][i] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * (32 * NI) + 32 * i + fr, k16 * 2 + fh));
 #pragma unroll
         for (int j = 0; j < MI; ++j)
           b[p][j] = *reinterpret_cast<const bf16x8*>(wb + p * WPL + lds_off(wm * (BM / 2) + 32 * j + fr, k16 * 2 + fh));
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
 #pragma unroll
       for (int t = 6 - NT; t < 6; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
           for (int j = 0; j < MI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[t] < NP ? PA[t] : 0][i], b[PB[t] < NP ? PB[t] : 0][j],
@@ -405,10 +408,10 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
     const int m = m0 + wm * (BM / 2) + 32 * j + fr;
     if (m >= M) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int t = n0 + wn * (32 * NI) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (t < T) {
           const size_t o = (size_t)t * M + m;
           y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
@@ -530,13 +533,13 @@ int launch_gemm_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const f
   return 0;
 }
 
-template <int TYPE, int NP, int NT, int BM>
-int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
-  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + GB_N - 1) / GB_N;
-  constexpr size_t lds = gemm_lds_bytes<NP, BM>();
+template <int TYPE, int NP, int NT, int BM, int BN>
+int launch_gemm_ws_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + BN - 1) / BN;
+  constexpr size_t lds = (size_t)2 * NP * (BM + BN) * LROW * sizeof(__bf16);
   static bool attr = false;
   if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_ws_kernel<TYPE, NP, NT, BM>),
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_ws_kernel<TYPE, NP, NT, BM, BN>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
@@ -564,15 +567,27 @@ int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
     }
   }
   if (S == 1) {
-    gemm_q_ws_kernel<TYPE, NP, NT, BM><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
+    gemm_q_ws_kernel<TYPE, NP, NT, BM, BN><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
   } else {
-    gemm_q_ws_kernel<TYPE, NP, NT, BM><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, part, nullptr, T, mtiles, ntiles);
+    gemm_q_ws_kernel<TYPE, NP, NT, BM, BN><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, part, nullptr, T, mtiles, ntiles);
     const size_t n = (size_t)T * w.rows;
     ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
   }
   TL_HIP(hipGetLastError());
   return 0;
 }
+// token tile by problem size: 64 tokens when there are no more (TL_GEMM_BN=128 keeps the wide tile for A/B runs)
+template <int TYPE, int NP, int NT, int BM>
+int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  static int narrow = -1;
+  if (narrow < 0) {
+    const char* e = getenv("TL_GEMM_BN");
+    narrow = !(e && atoi(e) == 128);
+  }
+  if (narrow && T <= 64) return launch_gemm_ws_bn<TYPE, NP, NT, BM, 64>(w, xp, ps, y, resid, T, s);
+  return launch_gemm_ws_bn<TYPE, NP, NT, BM, GB_N>(w, xp, ps, y, resid, T, s);
+}
+
 template <int TYPE, int BM>
 int launch_gemm_ws_bm(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                       hipStream_t s) {

@@ -34,6 +34,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
@@ -424,16 +425,11 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
 // planes[p][t][k] bf16, t < Tpad (rows >= T are never written: a token row only ever meets its own output row)
 enum SplitMode { SPLIT_PLAIN = 0, SPLIT_RMSNORM = 1, SPLIT_SWIGLU = 2 };
 
-__device__ __forceinline__ void store_split(float v, __bf16* planes, size_t plane_stride, size_t idx, int np) {
-  for (int p = 0; p < np; ++p) {
-    const __bf16 b = (__bf16)v;
-    planes[p * plane_stride + idx] = b;
-    v -= (float)b;
-  }
-}
-
-// one workgroup per token. RMSNORM: rmsnorm_batch_cpu (utils.cpp:613-646): x * rsqrt(mean(x^2) + eps) * w.
-// SWIGLU: the batched form of cpu_batch_processor.cpp:252-256: (g / (1 + exp(-g))) * u.
+// One workgroup per (token, 2048-column slice): 8 consecutive columns per thread, 16-byte plane stores. RMSNORM:
+// rmsnorm_batch_cpu (utils.cpp:613-646): x * rsqrt(mean(x^2) + eps) * w; every slice's workgroup sums the squares of the
+// whole row itself (same order in all of them). SWIGLU: the batched form of cpu_batch_processor.cpp:252-256:
+// (g / (1 + exp(-g))) * u. K is a multiple of 32.
+constexpr int SPLIT_SLICE = 2048;
 template <int MODE>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ aux,
                                                     __bf16* __restrict__ planes, size_t plane_stride, int K, int np,
@@ -450,11 +446,33 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
     __syncthreads();
     nf = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
   }
-  for (int i = threadIdx.x; i < K; i += 256) {
-    float v = xt[i];
-    if (MODE == SPLIT_RMSNORM) v = v * nf * aux[i];
-    if (MODE == SPLIT_SWIGLU) v = (v / (1.0f + expf(-v))) * aux[(size_t)t * K + i];
-    store_split(v, planes, plane_stride, (size_t)t * K + i, np);
+  const int i0 = blockIdx.y * SPLIT_SLICE + threadIdx.x * 8;
+  if (i0 >= K) return;
+  float v[8];
+  const f32x4 lo = *reinterpret_cast<const f32x4*>(xt + i0), hi = *reinterpret_cast<const f32x4*>(xt + i0 + 4);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] = lo[e];
+    v[4 + e] = hi[e];
+  }
+  if (MODE != SPLIT_PLAIN) {
+    const float* ap = MODE == SPLIT_RMSNORM ? aux + i0 : aux + (size_t)t * K + i0;
+    const f32x4 alo = *reinterpret_cast<const f32x4*>(ap), ahi = *reinterpret_cast<const f32x4*>(ap + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float a = e < 4 ? alo[e] : ahi[e - 4];
+      if (MODE == SPLIT_RMSNORM) v[e] = v[e] * nf * a;
+      else v[e] = (v[e] / (1.0f + expf(-v[e]))) * a;
+    }
+  }
+  for (int p = 0; p < np; ++p) {
+    bf16x8 b;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      b[e] = (__bf16)v[e];
+      v[e] -= (float)b[e];
+    }
+    *reinterpret_cast<bf16x8*>(planes + p * plane_stride + (size_t)t * K + i0) = b;
   }
 }
 
@@ -638,9 +656,11 @@ int tl_launch_split(int mode, const float* x, const float* aux, void* planes, si
   if (T == 0) return 0;
   const int np = planes_of_terms(terms);
   __bf16* pl = static_cast<__bf16*>(planes);
-  if (mode == SPLIT_RMSNORM) split_kernel<SPLIT_RMSNORM><<<T, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
-  else if (mode == SPLIT_SWIGLU) split_kernel<SPLIT_SWIGLU><<<T, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
-  else split_kernel<SPLIT_PLAIN><<<T, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  TL_REQUIRE(K > 0 && K % 8 == 0 && T <= 65535, "tl_launch_split: bad shape %d x %d", T, K);
+  const dim3 grid(T, (K + SPLIT_SLICE - 1) / SPLIT_SLICE);
+  if (mode == SPLIT_RMSNORM) split_kernel<SPLIT_RMSNORM><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  else if (mode == SPLIT_SWIGLU) split_kernel<SPLIT_SWIGLU><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  else split_kernel<SPLIT_PLAIN><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
   TL_HIP(hipGetLastError());
   return 0;
 }

@@ -316,7 +316,7 @@ def batch_leg(model, cfg, B, plen=16, steps=16, terms=6):
 
 def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3, world=1):
     """tokens/s of tl_model_prefill (MFMA GEMMs over the quantized weights, FP32-MFMA attention) for a T-token prompt;
-    executed bf16 MFMA flops = terms x the algorithmic GEMM flops 2*T*(layer weight elements)."""
+    executed bf16 MFMA flops = (MFMAs per product) x the algorithmic GEMM flops 2*T*(layer weight elements)."""
     toks = np.random.default_rng(1).integers(0, cfg["vocab"], T).astype(np.int32)
     model.set_prefill(terms=terms, min_batch=8)
     model.reset_kv()
@@ -329,10 +329,15 @@ def prefill_leg(model, S, cfg, mix, T, terms=6, reps=3, world=1):
         best = min(best, time.perf_counter() - t0)
     elems = sum(r * c for n, t, r, c in S.tensor_plan(cfg, mix) if n.startswith("blk.") and t != S.F32)
     flops = 2.0 * T * elems / world  # per GPU
-    return {"prompt_tokens": T, "mfma_terms": terms, "ms": round(best * 1e3, 2), "tokens_per_s": round(T / best, 1),
+    # MFMAs per product: the integer-plane GEMM multiplies EXACT integer weights (one bf16 plane) with the activation in
+    # 3 / 2 / 1 bf16 planes (FP32-grade / 2^-17 / plain bf16); TL_GEMM_INT=0 (exact-dequantization kernel) spends 6 / 3 / 1
+    per_product = {6: 3, 3: 2, 1: 1}[terms] if os.environ.get("TL_GEMM_INT", "1") != "0" else terms
+    return {"prompt_tokens": T, "mfma_terms": terms, "mfma_per_product": per_product,
+            "precision": {6: "fp32-grade", 3: "2^-17 per product", 1: "bf16 activations"}[terms],
+            "ms": round(best * 1e3, 2), "tokens_per_s": round(T / best, 1),
             "gemm_tflops_algorithmic": round(flops / best / 1e12, 1),
-            "bf16_mfma_tflops_executed": round(flops * terms / best / 1e12, 1),
-            "frac_of_bf16_dense_peak": round(flops * terms / best / 2.5e15, 4),
+            "bf16_mfma_tflops_executed": round(flops * per_product / best / 1e12, 1),
+            "frac_of_bf16_dense_peak": round(flops * per_product / best / 2.5e15, 4),
             "note": "whole prefill wall time incl. attention and glue (rank 0's clock; TFLOP/s per GPU); per-kernel MFMA "
                     "busy counters: profiles/"}
 

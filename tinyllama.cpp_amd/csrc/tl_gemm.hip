@@ -421,6 +421,255 @@ __global__ __launch_bounds__(WS_THREADS) void gemm_q_ws_kernel(QW w, const __bf1
   }
 }
 
+
+// ---- the integer-plane form (default) --------------------------------------------------------------------------------------
+// A quantized weight is (scale of its sub-block) x (small integer) [- (min of its sub-block)], and the integers (Q4_K
+// 0..15, Q6_K -32..31, Q8 -128..127) are EXACT in bf16. So the weights need no FP32 dequantization and no three-way split:
+// the producers unpack the integers into ONE bf16 plane, the matrix cores form  S[row][tok] = sum_k q[row][k] x[tok][k]
+// over the 16 columns of an MFMA (Q6_K's scale granularity; Q4_K / Q8 blocks are 32 = two of them) with the activation
+// split into its 1..3 bf16 planes -- 3 MFMAs per FP32-grade product instead of 6 -- and the consumers fold the scales in
+// on the VALU:  acc += (d*sc)[row] * S   and, for Q4_K,  acc -= (dmin*m)[row] * sum_k x[tok][k]  per 32-column step (the
+// block sums of x come from split_kernel). This is the decode GEMV's factorisation (tl_gemv.hip Chunk::dot), so batched
+// and token-by-token paths round alike; d*sc and dmin*m are the reference's separately rounded FP32 products.
+// Producers shrink to a byte unpack (no exact-dequant arithmetic, one LDS plane instead of three).
+// LDS per buffer: W [64][32] bf16 | X [NPX][BN][32] bf16 | sA [64][2] f32 (scale per row and 16-column half) |
+// sB [64] f32 (Q4_K: dmin*m) | sx [BN] f32 (Q4_K: block sums of x).
+template <int TYPE>
+__device__ __forceinline__ bf16x8 unpack8(const Raw8& r, int q) {
+  bf16x8 o;
+  if (TYPE == TL_Q4_K) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned byte = (r.a >> (8 * t)) & 0xffu;
+      o[t] = (__bf16)(float)(byte & 15u);
+      o[4 + t] = (__bf16)(float)(byte >> 4);
+    }
+  } else if (TYPE == TL_Q6_K) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int part = i >> 2, t = i & 3, g = 2 * (q & 1) + part;
+      const unsigned lo = (r.a >> (8 * t + 4 * part)) & 15u;
+      const unsigned hi = (r.b >> (8 * t + 2 * g)) & 3u;
+      o[i] = (__bf16)(float)((int)(lo | (hi << 4)) - 32);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned v = i < 4 ? r.a : r.b;
+      o[i] = (__bf16)(float)(int)(signed char)((v >> (8 * (i & 3))) & 0xffu);
+    }
+  }
+  return o;
+}
+
+template <int NPX, int BN, int BM>
+constexpr size_t gemm_qi_lds_bytes() {
+  return (size_t)2 * ((BM + NPX * BN) * LROW * sizeof(__bf16) + (BM * 3 + BN) * sizeof(float));
+}
+
+// BM = 128 (two 32-row fragments per consumer wave) halves the activation-fragment reads per MFMA: with half the MFMAs of
+// the exact-dequantization kernel this form is bound by LDS reads at BM = 64; its LDS image is small enough for two
+// workgroups per CU at BM = 128 (the three-weight-plane kernel's is not).
+#ifndef TL_QI_WAVES
+#define TL_QI_WAVES 2
+#endif
+template <int TYPE, int NPX, int BN, int BM>
+__global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
+                                                                const float* __restrict__ xsum, int tpad,
+                                                                float* __restrict__ y, const float* __restrict__ resid,
+                                                                int T, int mtiles, int ntiles) {
+  constexpr int NI = BN / 64, MI = BM / 64;
+  constexpr bool PER16 = TYPE == TL_Q6_K;  // scale granularity: 16 columns (one MFMA) or the whole 32-column step
+  constexpr int WPL = BM * LROW, XPL = BN * LROW;
+  constexpr size_t BUF_BYTES = (WPL + NPX * XPL) * sizeof(__bf16) + (BM * 3 + BN) * sizeof(float);
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int M = w.rows, K = w.cols;
+  const int total = mtiles * ntiles;
+  int tile = blockIdx.x;
+  if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int nt = tile / mtiles, mt = tile - nt * mtiles;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk_all = K / GB_K, kper = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int kbase = (int)blockIdx.y * kper;
+  const int nk = nk_all - kbase < kper ? nk_all - kbase : kper, last = kbase + nk - 1;
+  const int nk3 = (nk + 2) / 3 * 3;
+  if (gridDim.y > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
+  auto wbuf = [&](int b) { return reinterpret_cast<__bf16*>(lds_raw + (size_t)b * BUF_BYTES); };
+  auto fbuf = [&](int b) {
+    return reinterpret_cast<float*>(lds_raw + (size_t)b * BUF_BYTES + (WPL + NPX * XPL) * sizeof(__bf16));
+  };
+  if (threadIdx.x >= 256) {
+    // ---------------- producers ----------------
+    const int tid = threadIdx.x - 256;
+    const int wrow = tid >> 2, wq = tid & 3;
+    int grow[MI];
+#pragma unroll
+    for (int j = 0; j < MI; ++j) grow[j] = m0 + wrow + 64 * j < M ? m0 + wrow + 64 * j : M - 1;
+    const int xr0 = tid >> 2, xs = tid & 3;
+    const __bf16* xg0 = xp + (size_t)(n0 + xr0) * K + xs * 8;
+    const float* sg = xsum + n0 + (tid < BN ? tid : 0);  // block sums of x: [K / 32][tpad]
+    struct Regs {
+      Raw8 rw[MI];
+      bf16x8 rx[NPX][NI];
+      float sx;
+    };
+    Regs s0, s1, s2;
+    auto fetch = [&](Regs& g, int kn) {
+      kn += kbase;
+      kn = kn < last ? kn : last;
+#pragma unroll
+      for (int j = 0; j < MI; ++j) g.rw[j] = load8<TYPE>(w, grow[j], kn, wq);
+#pragma unroll
+      for (int p = 0; p < NPX; ++p)
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+          g.rx[p][i] = *reinterpret_cast<const bf16x8*>(xg0 + (size_t)(64 * i) * K + p * plane_stride + (size_t)kn * GB_K);
+      if (TYPE == TL_Q4_K) g.sx = sg[(size_t)kn * tpad];
+    };
+    auto stage = [&](const Regs& g, int buf, int kn) {
+      kn += kbase;
+      kn = kn < last ? kn : last;
+      __bf16* wb = wbuf(buf);
+      __bf16* xb = wb + WPL;
+      float* fb = fbuf(buf);
+#pragma unroll
+      for (int j = 0; j < MI; ++j) {
+#pragma clang fp contract(off)
+        const int row = wrow + 64 * j;
+        const Raw8& r = g.rw[j];
+        *reinterpret_cast<bf16x8*>(wb + lds_off(row, wq)) = unpack8<TYPE>(r, wq);
+        if (TYPE == TL_Q4_K) {
+          if (wq == 0) {
+            const int c = kn & 7;
+            const float d = h2f(r.h[0] & 0xffffu), dmin = h2f(r.h[0] >> 16);
+            const unsigned sc = ((r.h[1] >> (4 * c)) & 15u) | (((r.h[3] >> (2 * c)) & 3u) << 4);
+            const unsigned mn = ((r.h[2] >> (4 * c)) & 15u) | (((r.h[3] >> (16 + 2 * c)) & 3u) << 4);
+            const float d1 = __fmul_rn(d, (float)sc);
+            fb[2 * row] = d1;
+            fb[2 * row + 1] = d1;
+            fb[2 * BM + row] = __fmul_rn(dmin, (float)mn);
+          }
+        } else if (TYPE == TL_Q6_K) {
+          if ((wq & 1) == 0)  // quarters 0 and 2 carry the scale bytes of the two 16-column halves
+            fb[2 * row + (wq >> 1)] = __fmul_rn(h2f(r.h[1]), (float)(int)(signed char)(r.h[0] & 0xffu));
+        } else {
+          if (wq == 0) {
+            const float d = h2f_scale(r.h[0]);
+            fb[2 * row] = d;
+            fb[2 * row + 1] = d;
+          }
+        }
+      }
+      if (TYPE == TL_Q4_K && tid < BN) fb[3 * BM + tid] = g.sx;
+#pragma unroll
+      for (int p = 0; p < NPX; ++p)
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0 + 64 * i, xs)) = g.rx[p][i];
+    };
+    fetch(s0, 0);
+    fetch(s1, 1);
+    fetch(s2, 2);
+    stage(s0, 0, 0);
+    __syncthreads();
+    for (int kk = 0; kk < nk3; kk += 3) {
+      fetch(s0, kk + 3);
+      stage(s1, (kk + 1) & 1, kk + 1);
+      __syncthreads();
+      fetch(s1, kk + 4);
+      stage(s2, (kk + 2) & 1, kk + 2);
+      __syncthreads();
+      fetch(s2, kk + 5);
+      stage(s0, (kk + 3) & 1, kk + 3);
+      __syncthreads();
+    }
+    return;
+  }
+  // ---------------- consumers: wave = BN/2 tokens x BM/2 rows ----------------
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int lrow0 = wm * (BM / 2) + fr;  // this lane's weight row of fragment j: lrow0 + 32 * j
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  for (int kk = 0; kk < nk3; ++kk) {
+    if (kk >= nk) {  // uniform
+      __syncthreads();
+      continue;
+    }
+    const __bf16* wb = wbuf(kk & 1);
+    const __bf16* xb = wb + WPL;
+    const float* fb = fbuf(kk & 1);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      f32x16 t[MI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) t[j] = zero;
+#pragma unroll
+      for (int k16 = 0; k16 < 2; ++k16) {
+        bf16x8 a[NPX];
+#pragma unroll
+        for (int p = 0; p < NPX; ++p)
+          a[p] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * (32 * NI) + 32 * i + fr, k16 * 2 + fh));
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const bf16x8 b = *reinterpret_cast<const bf16x8*>(wb + lds_off(lrow0 + 32 * j, k16 * 2 + fh));
+#pragma unroll
+          for (int p = NPX - 1; p >= 0; --p) t[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p], b, t[j], 0, 0, 0);  // smallest plane first
+          if (PER16) {
+            const float sa = fb[2 * (lrow0 + 32 * j) + k16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(sa, t[j][e], acc[i][j][e]);
+            t[j] = zero;
+          }
+        }
+      }
+      if (!PER16) {
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const float sa = fb[2 * (lrow0 + 32 * j)];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(sa, t[j][e], acc[i][j][e]);
+        }
+      }
+      if (TYPE == TL_Q4_K) {
+        const float* sx = fb + 3 * BM;
+        f32x4 v[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(sx + wn * (32 * NI) + 32 * i + 8 * g4 + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const float nsb = -fb[2 * BM + lrow0 + 32 * j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(nsb, v[e >> 2][e & 3], acc[i][j][e]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + lrow0 + 32 * j;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = n0 + wn * (32 * NI) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (t < T) {
+          const size_t o = (size_t)t * M + m;
+          y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
+        }
+      }
+  }
+}
+
 // ---- producers of the activation planes ----------------------------------------------------------------------------
 // planes[p][t][k] bf16, t < Tpad (rows >= T are never written: a token row only ever meets its own output row)
 enum SplitMode { SPLIT_PLAIN = 0, SPLIT_RMSNORM = 1, SPLIT_SWIGLU = 2 };
@@ -433,7 +682,7 @@ constexpr int SPLIT_SLICE = 2048;
 template <int MODE>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ aux,
                                                     __bf16* __restrict__ planes, size_t plane_stride, int K, int np,
-                                                    float eps) {
+                                                    float eps, float* __restrict__ xsum, int tpad) {
   __shared__ float red[4];
   const int t = blockIdx.x;
   const float* xt = x + (size_t)t * K;
@@ -465,6 +714,11 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
       else v[e] = (v[e] / (1.0f + expf(-v[e]))) * a;
     }
   }
+  // sum of the 32-column block (4 threads): the integer-plane GEMM folds Q4_K's block minimum in through it
+  float bs = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+  bs += __shfl_xor(bs, 1);
+  bs += __shfl_xor(bs, 2);
+  if ((threadIdx.x & 3) == 0) xsum[(size_t)(i0 >> 5) * tpad + t] = bs;
   for (int p = 0; p < np; ++p) {
     bf16x8 b;
 #pragma unroll
@@ -606,6 +860,69 @@ int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
   return launch_gemm_ws_bn<TYPE, NP, NT, BM, GB_N>(w, xp, ps, y, resid, T, s);
 }
 
+template <int TYPE, int NPX, int BN, int BM>
+int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + BN - 1) / BN;
+  constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
+  static bool attr = false;
+  if (!attr) {
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qi_ws_kernel<TYPE, NPX, BN, BM>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
+  const int tpad = (int)tl_gemm_padded_tokens(T);
+  const int tiles = mtiles * ntiles, nk_all = w.cols / GB_K;
+  int S = 1;  // split K as in launch_gemm_ws_bn
+  if (ksplit_enabled() && tiles < 2 * gemm_num_cus()) {
+    S = (2 * gemm_num_cus() + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+    if (S > nk_all / 12) S = nk_all / 12;
+    if (S < 1) S = 1;
+    const int kper = (nk_all + S - 1) / S;
+    S = (nk_all + kper - 1) / kper;
+  }
+  float* part = nullptr;
+  if (S > 1) {
+    const int slot = ksplit_slot(s);
+    if (slot < 0) S = 1;
+    else {
+      void* p = nullptr;
+      TL_TRY(tl_scratch(slot, sizeof(float) * (size_t)S * T * w.rows, &p));
+      part = static_cast<float*>(p);
+    }
+  }
+  if (S == 1) {
+    gemm_qi_ws_kernel<TYPE, NPX, BN, BM><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, xsum, tpad, y, resid, T, mtiles, ntiles);
+  } else {
+    gemm_qi_ws_kernel<TYPE, NPX, BN, BM><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, xsum, tpad, part, nullptr, T, mtiles, ntiles);
+    const size_t n = (size_t)T * w.rows;
+    ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
+  }
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+template <int TYPE, int NPX, int BM>
+int launch_gemm_qi_np(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  static int narrow_always = -1;
+  if (narrow_always < 0) {
+    const char* e = getenv("TL_GEMM_QI_BN");  // 64: 64-token tiles for every problem size (A/B runs)
+    narrow_always = e && atoi(e) == 64;
+  }
+  return (T <= 64 || narrow_always) ? launch_gemm_qi_bn<TYPE, NPX, 64, BM>(w, xp, ps, y, resid, T, s)
+                                    : launch_gemm_qi_bn<TYPE, NPX, GB_N, BM>(w, xp, ps, y, resid, T, s);
+}
+template <int TYPE>
+int launch_gemm_qi(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms, int bm,
+                   hipStream_t s) {
+  if (bm == 128) {
+    if (terms == 3) return launch_gemm_qi_np<TYPE, 2, 128>(w, xp, ps, y, resid, T, s);
+    return launch_gemm_qi_np<TYPE, 3, 128>(w, xp, ps, y, resid, T, s);
+  }
+  if (terms == 3) return launch_gemm_qi_np<TYPE, 2, 64>(w, xp, ps, y, resid, T, s);
+  return launch_gemm_qi_np<TYPE, 3, 64>(w, xp, ps, y, resid, T, s);
+}
+
 template <int TYPE, int BM>
 int launch_gemm_ws_bm(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                       hipStream_t s) {
@@ -626,13 +943,17 @@ template <int TYPE>
 int launch_gemm_typed(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                       hipStream_t s) {
   // 128-row tiles when they still give every CU two workgroups' worth of tiles, else 64-row tiles
-  static int forced = -1, ws = -1;
+  static int forced = -1, ws = -1, integer_planes = 1;
   if (forced < 0) {
+    const char* q = getenv("TL_GEMM_INT");  // 0: the exact-dequantization kernels (three weight planes, 6 / 3 / 1 MFMAs)
+    integer_planes = q ? atoi(q) != 0 : 1;
     const char* e = getenv("TL_GEMM_BM");
     forced = e ? atoi(e) : 0;
     const char* v = getenv("TL_GEMM_WS");
     ws = v ? atoi(v) : 1;  // default: the wave-specialised kernel; TL_GEMM_WS=0 selects the unified one (A/B runs)
   }
+  // (one MFMA per product leaves nothing to save on the matrix cores: the plain bf16 form stays on the dequantizing kernel)
+  if (integer_planes && terms != 1) return launch_gemm_qi<TYPE>(w, xp, ps, y, resid, T, terms, forced == 64 ? 64 : 128, s);
   const long tiles128 = (long)((w.rows + 127) / 128) * ((T + GB_N - 1) / GB_N);
   if (ws) {  // 128-row tiles halve the LDS fragment traffic per MFMA but leave one workgroup per CU: measured 14 % slower
     const bool big = forced == 128;
@@ -650,6 +971,9 @@ int g_gemm_terms = 6;
 
 int tl_gemm_default_terms() { return g_gemm_terms; }
 size_t tl_gemm_padded_tokens(int T) { return (size_t)((T + GB_N - 1) / GB_N) * GB_N; }
+// bytes of an activation-plane buffer with plane_stride = padded tokens x columns: three bf16 planes + the FP32 sums of
+// every 32-column block
+size_t tl_gemm_planes_bytes(size_t plane_stride) { return 3 * plane_stride * sizeof(__bf16) + plane_stride / 32 * sizeof(float); }
 
 int tl_launch_split(int mode, const float* x, const float* aux, void* planes, size_t plane_stride, int T, int K,
                     int terms, float eps, hipStream_t s) {
@@ -658,9 +982,11 @@ int tl_launch_split(int mode, const float* x, const float* aux, void* planes, si
   __bf16* pl = static_cast<__bf16*>(planes);
   TL_REQUIRE(K > 0 && K % 8 == 0 && T <= 65535, "tl_launch_split: bad shape %d x %d", T, K);
   const dim3 grid(T, (K + SPLIT_SLICE - 1) / SPLIT_SLICE);
-  if (mode == SPLIT_RMSNORM) split_kernel<SPLIT_RMSNORM><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
-  else if (mode == SPLIT_SWIGLU) split_kernel<SPLIT_SWIGLU><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
-  else split_kernel<SPLIT_PLAIN><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps);
+  float* xsum = reinterpret_cast<float*>(pl + 3 * plane_stride);  // [K / 32][padded tokens], behind the three planes
+  const int tpad = (int)tl_gemm_padded_tokens(T);
+  if (mode == SPLIT_RMSNORM) split_kernel<SPLIT_RMSNORM><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad);
+  else if (mode == SPLIT_SWIGLU) split_kernel<SPLIT_SWIGLU><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad);
+  else split_kernel<SPLIT_PLAIN><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad);
   TL_HIP(hipGetLastError());
   return 0;
 }
@@ -714,7 +1040,8 @@ extern "C" int tl_matmul_q(const tl_qweight* w, const float* x_dev, float* y_dev
   const int terms = g_gemm_terms, np = planes_of_terms(terms);
   const size_t ps = tl_gemm_padded_tokens(num_tokens) * (size_t)w->cols;
   void* ws = nullptr;
-  TL_TRY(tl_scratch(TL_SCRATCH_GEMM_PLANES, ps * np * sizeof(__bf16), &ws));
+  (void)np;
+  TL_TRY(tl_scratch(TL_SCRATCH_GEMM_PLANES, tl_gemm_planes_bytes(ps), &ws));
   TL_TRY(tl_launch_split(SPLIT_PLAIN, x_dev, nullptr, ws, ps, num_tokens, w->cols, terms, 0.f, s));
   return tl_launch_gemm_q(qw_view(w), ws, ps, y_dev, nullptr, num_tokens, terms, s);
 }

@@ -146,6 +146,7 @@ int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s);
 // 1..3 bf16 planes [plane][padded tokens][cols]; terms = MFMAs per product (1, 3 or 6)
 int tl_gemm_default_terms();
 size_t tl_gemm_padded_tokens(int T);
+size_t tl_gemm_planes_bytes(size_t plane_stride);  // three bf16 planes + FP32 block sums
 // mode 0: planes = split(x[T][K]); 1: split(rmsnorm_batch(x, aux = weight[K], eps)); 2: split(swiglu(x, aux[T][K]))
 int tl_launch_split(int mode, const float* x, const float* aux, void* planes, size_t plane_stride, int T, int K,
                     int terms, float eps, hipStream_t s);

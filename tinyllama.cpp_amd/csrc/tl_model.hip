@@ -944,8 +944,8 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
     TL_HIP(hipMalloc(&p.ab, sizeof(float) * cap * (size_t)m->qd_l));
     TL_HIP(hipMalloc(&p.gb, sizeof(float) * cap * (size_t)m->I_l));
     TL_HIP(hipMalloc(&p.ub, sizeof(float) * cap * (size_t)m->I_l));
-    TL_HIP(hipMalloc(&p.planes, 2 * 3 * p.plane_stride));
-    TL_HIP(hipMemsetAsync(p.planes, 0, 2 * 3 * p.plane_stride, m->stream));
+    TL_HIP(hipMalloc(&p.planes, tl_gemm_planes_bytes(p.plane_stride)));
+    TL_HIP(hipMemsetAsync(p.planes, 0, tl_gemm_planes_bytes(p.plane_stride), m->stream));
     TL_HIP(hipStreamCreateWithFlags(&p.side, hipStreamNonBlocking));
     TL_HIP(hipEventCreateWithFlags(&p.fork, hipEventDisableTiming));
     TL_HIP(hipEventCreateWithFlags(&p.join, hipEventDisableTiming));

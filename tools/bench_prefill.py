@@ -4,7 +4,7 @@
     python tools/bench_prefill.py [--workload llama-3-8b] [--lens 128,512,2048] [--terms 6,3,1] [--reps 3]
 
 Algorithmic GEMM flops per token = 2 * (weight elements of all layer projections) (the lm_head runs for the
-last token only, as a GEMV); executed bf16 MFMA flops = terms x that."""
+last token only, as a GEMV); executed bf16 MFMA flops = (MFMAs per product: 3 / 2 / 1 for terms 6 / 3 / 1 with the integer-plane GEMM) x that."""
 import argparse
 import json
 import os
@@ -62,7 +62,7 @@ def main():
             attn_flops = 4.0 * (T * (T + 1) / 2) * nh * hd * cfg["n_layers"]
             row = {"T": T, "terms": terms, "ms": round(best * 1e3, 2), "tokens_per_s": round(T / best, 1),
                    "gemm_tflops_algorithmic": round(gemm_flops / best / 1e12, 1),
-                   "mfma_bf16_tflops_executed": round(gemm_flops * terms / best / 1e12, 1),
+                   "mfma_bf16_tflops_executed": round(gemm_flops * ({6: 3, 3: 2, 1: 1}[terms] if os.environ.get("TL_GEMM_INT", "1") != "0" else terms) / best / 1e12, 1),
                    "attn_gflop": round(attn_flops / 1e9, 1)}
             out.append(row)
             print(json.dumps(row), flush=True)

@@ -473,6 +473,9 @@ constexpr size_t gemm_qi_lds_bytes() {
 #ifndef TL_QI_WAVES
 #define TL_QI_WAVES 2
 #endif
+#ifndef TL_QI_SETS
+#define TL_QI_SETS 3
+#endif
 template <int TYPE, int NPX, int BN, int BM>
 __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
                                                                 const float* __restrict__ xsum, int tpad,
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW 
   const int nk_all = K / GB_K, kper = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int kbase = (int)blockIdx.y * kper;
   const int nk = nk_all - kbase < kper ? nk_all - kbase : kper, last = kbase + nk - 1;
-  const int nk3 = (nk + 2) / 3 * 3;
+  const int nk3 = (nk + TL_QI_SETS - 1) / TL_QI_SETS * TL_QI_SETS;  // both roles run a multiple of the rotation length
   if (gridDim.y > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
   auto wbuf = [&](int b) { return reinterpret_cast<__bf16*>(lds_raw + (size_t)b * BUF_BYTES); };
   auto fbuf = [&](int b) {
@@ -513,7 +516,11 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW 
       bf16x8 rx[NPX][NI];
       float sx;
     };
+#if TL_QI_SETS == 3
     Regs s0, s1, s2;
+#else
+    Regs s0, s1;
+#endif
     auto fetch = [&](Regs& g, int kn) {
       kn += kbase;
       kn = kn < last ? kn : last;
@@ -566,6 +573,7 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW 
 #pragma unroll
         for (int i = 0; i < NI; ++i) *reinterpret_cast<bf16x8*>(xb + p * XPL + lds_off(xr0 + 64 * i, xs)) = g.rx[p][i];
     };
+#if TL_QI_SETS == 3
     fetch(s0, 0);
     fetch(s1, 1);
     fetch(s2, 2);
@@ -582,6 +590,20 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW 
       stage(s0, (kk + 3) & 1, kk + 3);
       __syncthreads();
     }
+#else  // two register sets: loads two steps ahead (fewer registers: two workgroups per CU)
+    fetch(s0, 0);
+    fetch(s1, 1);
+    stage(s0, 0, 0);
+    __syncthreads();
+    for (int kk = 0; kk < nk3; kk += 2) {
+      fetch(s0, kk + 2);
+      stage(s1, (kk + 1) & 1, kk + 1);
+      __syncthreads();
+      fetch(s1, kk + 3);
+      stage(s0, kk & 1, kk + 2);
+      __syncthreads();
+    }
+#endif
     return;
   }
   // ---------------- consumers: wave = BN/2 tokens x BM/2 rows ----------------

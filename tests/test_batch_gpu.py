@@ -112,6 +112,35 @@ def test_packed_prefill_of_all_prompts(pkg, oracle, shape, mix, lens):
     om.close()
 
 
+def test_batch_long_contexts_and_eight_head_groups(pkg, oracle):
+    """TinyLlama-1.1B's attention geometry (head_dim 64, 8 query heads per kv head: two workgroups per (kv head, token))
+    at 2 layers, with contexts of 70..150 rows (several 64-row passes of the batched decode attention) next to a short one."""
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg = dict(pkg.synth.SHAPES["tinyllama-1.1b"], n_layers=2, vocab=2048, max_pos=256)
+    cfg, tensors = pkg.synth.build_model(cfg, "q4_k_m", seed=23)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    rng = np.random.default_rng(6)
+    lens = [150, 70, 4]
+    prompts = [rng.integers(0, cfg["vocab"], n).astype(np.int32) for n in lens]
+    n_steps = 5
+    want = [oracle_run(om, p, n_steps) for p in prompts]
+    m.batch_init(4)
+    logits, ids = m.batch_prefill_packed(prompts, slots=[2, 0, 3])
+    for i in range(3):
+        assert close(logits[i], want[i][1][0], LOGIT_TOL).all(), (i, np.abs(logits[i] - want[i][1][0]).max())
+    toks, pos = [int(x) for x in ids], list(lens)
+    for step in range(1, n_steps):
+        lg, nxt = m.batch_decode(toks, pos, [2, 0, 3])
+        for i in range(3):
+            assert close(lg[i], want[i][1][step], LOGIT_TOL).all(), (step, i, np.abs(lg[i] - want[i][1][step]).max())
+            assert nxt[i] == want[i][0][step]
+        toks, pos = [int(x) for x in nxt], [p + 1 for p in pos]
+    m.free()
+    om.close()
+
+
 def test_packed_prefill_rejects_bad_batches(pkg):
     from tinyllama_cpp_amd import engine as E
     from tinyllama_cpp_amd.capi import TlError, check, lib

@@ -6,7 +6,9 @@
 // start_pos + i) attends positions 0..start_pos+i of its kv head's cache rows; scores = (q . k) * scale, softmax
 // with max-subtraction and 1/(sum + 1e-9), out = sum p v.
 //
-// Shape: one wave per (32-query tile, head); the positions are walked in tiles of 32 with an online softmax.
+// Shape: one workgroup of PF_NW waves per (32-query tile, head); the key tiles of 32 positions are dealt round-robin to the
+// waves, each walks its tiles with an online softmax of its own, and the waves' (max, sum, O) are merged through LDS in
+// wave order at the end (deterministic).
 //   S^T[pos][q] = K Q^T : A = K tile, B = Q^T. The summation index d is permuted so that lane half h owns
 //     d in [HD/2*h, HD/2*(h+1)): a lane's K operand is then ONE contiguous half row of the cache (16-B loads straight
 //     from global memory, no LDS), and its Q operand a half row kept in registers for the whole kernel.
@@ -26,13 +28,18 @@ namespace {
 // position (row of the 32x32 result) held in accumulator register e of lane half h
 __device__ __forceinline__ int acc_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
 
+constexpr int PF_NW = 4;
+
 template <int HD>
-__global__ __launch_bounds__(64) void attn_prefill_mfma_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+__global__ __launch_bounds__(64 * PF_NW) void attn_prefill_mfma_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out,
                                                                int T, int start_pos, int nh, int nkv, float scale) {
   constexpr int HH = HD / 2;   // d range of a lane half
   constexpr int DB = HD / 32;  // 32-wide d blocks of the output
-  const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+  __shared__ float sm_m[PF_NW][32], sm_l[PF_NW][32];
+  __shared__ __attribute__((aligned(16))) float sm_o[32][HD];
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int wave = threadIdx.x >> 6;
   const int q0 = blockIdx.x * 32, head = blockIdx.y;
   const int kvh = head / (nh / nkv);
   const int kv_dim = nkv * HD;
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(64) void attn_prefill_mfma_kernel(const float* __re
 
   const int last_q = q0 + 31 < T ? q0 + 31 : T - 1;
   const int ntile = (start_pos + last_q) / 32 + 1;  // tiles holding positions <= the last query's position
-  for (int tile = 0; tile < ntile; ++tile) {
+  for (int tile = wave; tile < ntile; tile += PF_NW) {
     const int p0 = tile * 32;
     // ---- S^T = K Q^T over d ---------------------------------------------------------------------------------
     const int krow = p0 + r < len ? p0 + r : len - 1;
@@ -83,13 +90,13 @@ __global__ __launch_bounds__(64) void attn_prefill_mfma_kernel(const float* __re
       tmax = fmaxf(tmax, s[e]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-    const float mnew = fmaxf(mrun, tmax);  // finite: position 0 is visible to every query in tile 0
+    const float mnew = fmaxf(mrun, tmax);  // may still be -inf: a wave's first tiles can lie wholly behind a query
     const float corr = mrun == -INFINITY ? 0.f : expf(mrun - mnew);
     mrun = mnew;
     float psum = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      s[e] = s[e] == -INFINITY ? 0.f : expf(s[e] - mnew);
+      s[e] = s[e] == -INFINITY ? 0.f : expf(s[e] - mnew);  // (s finite implies mnew finite)
       psum += s[e];
     }
     lrun = lrun * corr + psum;
@@ -112,18 +119,48 @@ __global__ __launch_bounds__(64) void attn_prefill_mfma_kernel(const float* __re
       for (int b = 0; b < DB; ++b) o[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(s[e], vp[32 * b], o[b], 0, 0, 0);
     }
   }
-  // ---- out[q][d] = O / (sum + 1e-9) -------------------------------------------------------------------------
+  // ---- merge the waves: M = max_w m_w, L = sum_w l_w e^(m_w - M), O = sum_w O_w e^(m_w - M), in wave order -----------
   const float ltot = lrun + __shfl_xor(lrun, 32);
-  const float inv = 1.0f / (ltot + 1e-9f);
+  if (h == 0) {
+    sm_m[wave][r] = mrun;
+    sm_l[wave][r] = ltot;
+  }
+  __syncthreads();
+  float fac[16];  // this wave's factor for the 16 queries whose O rows this lane holds
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int row = acc_row(e, h);
-    const float c = __shfl(inv, row);
-    if (q0 + row < T) {
-      float* op = out + ((size_t)(q0 + row) * nh + head) * HD + r;
+    float M = sm_m[0][row];
 #pragma unroll
-      for (int b = 0; b < DB; ++b) op[32 * b] = o[b][e] * c;
+    for (int w = 1; w < PF_NW; ++w) M = fmaxf(M, sm_m[w][row]);
+    const float mw = sm_m[wave][row];
+    fac[e] = mw == -INFINITY ? 0.f : expf(mw - M);  // M is finite: position 0 is visible to every query (wave 0, tile 0)
+  }
+  for (int w = 0; w < PF_NW; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = acc_row(e, h);
+#pragma unroll
+        for (int b = 0; b < DB; ++b) {
+          const float v = o[b][e] * fac[e];
+          sm_o[row][32 * b + r] = w == 0 ? v : sm_o[row][32 * b + r] + v;
+        }
+      }
     }
+    __syncthreads();
+  }
+  // ---- out[q][d] = O / (L + 1e-9): 256 threads over 32 x HD values ---------------------------------------------
+  for (int i = threadIdx.x; i < 32 * HD; i += 64 * PF_NW) {
+    const int row = i / HD, d = i % HD;
+    if (q0 + row >= T) continue;
+    float M = sm_m[0][row];
+#pragma unroll
+    for (int w = 1; w < PF_NW; ++w) M = fmaxf(M, sm_m[w][row]);
+    float L = 0.f;
+#pragma unroll
+    for (int w = 0; w < PF_NW; ++w) L += sm_m[w][row] == -INFINITY ? 0.f : sm_l[w][row] * expf(sm_m[w][row] - M);
+    out[((size_t)(q0 + row) * nh + head) * HD + d] = sm_o[row][d] * (1.0f / (L + 1e-9f));
   }
 }
 
@@ -138,7 +175,7 @@ int tl_launch_attn_prefill_mfma(const float* q, const float* kc, const float* vc
                                 int nh, int nkv, int hd, float scale, hipStream_t s) {
   TL_REQUIRE(tl_attn_prefill_mfma_supported(nh, nkv, hd), "tl_launch_attn_prefill_mfma: unsupported head shape");
   if (T == 0) return 0;
-  const dim3 grid((T + 31) / 32, nh), block(64);
+  const dim3 grid((T + 31) / 32, nh), block(64 * PF_NW);
   if (hd == 128) attn_prefill_mfma_kernel<128><<<grid, block, 0, s>>>(q, kc, vc, out, T, start_pos, nh, nkv, scale);
   else attn_prefill_mfma_kernel<64><<<grid, block, 0, s>>>(q, kc, vc, out, T, start_pos, nh, nkv, scale);
   TL_HIP(hipGetLastError());

@@ -33,7 +33,7 @@ def oracle_run(om, prompt, n_steps):
     return np.array(ids, np.int32), np.stack(rows)
 
 
-@pytest.mark.parametrize("gemv_max", ["12", "0", "3"])
+@pytest.mark.parametrize("gemv_max", ["8", "0", "3"])
 @pytest.mark.parametrize("shape,mix", [("tiny-gqa", "q4_k_m"), ("tiny", "q6_k"), ("tiny-tp", "q8_0")])
 def test_batch_matches_single_sequence_oracle(pkg, oracle, monkeypatch, shape, mix, gemv_max):
     """gemv_max: steps with at most that many sequences use multi-vector GEMVs, larger ones matrix-core GEMMs

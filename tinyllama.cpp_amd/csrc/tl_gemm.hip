@@ -692,6 +692,234 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW 
   }
 }
 
+// ---- the direct form for few tokens (multi-sequence decode steps, short prompts) ----------------------------------------
+// With <= 64 tokens a weight byte meets so few MFMAs that the kernel above is bound by its four producer waves (byte
+// unpack + LDS write of every weight: the whole weight set passes in ~8 ms whatever the token count). Here the weights
+// never touch LDS: EVERY wave loads the raw bytes of its own 32 rows straight into registers (QD_SETS steps ahead),
+// unpacks them into the MFMA operand it feeds itself, and applies the scales of its own rows from the same registers;
+// only the activation tile (NPX planes x 32*NI tokens, + the block sums for Q4_K) is staged through LDS, cooperatively,
+// one step ahead, one barrier per step. A step is 64 columns = two 32-weight chunks: lane (row fr, half fh) loads the
+// WHOLE chunk 2s + fh of its row with one 16-byte load (two for Q8), and v_permlane32_swap hands the quarters round so
+// that both halves of the wave hold the operand of one chunk (an MFMA must not mix chunks: their scales differ).
+// Same arithmetic per (row, token) as gemm_qi_ws_kernel: S per 16 columns on the matrix cores, acc += (d*sc) * S,
+// acc -= (dmin*m) * sum(x) on the VALU. Workgroup = NW waves x 32 rows; K split over gridDim.y slices as above.
+// K must be a multiple of 64.
+#ifndef TL_QD_SETS
+#define TL_QD_SETS 3
+#endif
+constexpr int QD_SETS = TL_QD_SETS;  // weight register sets = 64-column steps a wave's loads run ahead
+__device__ __forceinline__ u32x2 half_swap(unsigned a, unsigned b) {  // -> {[a.lo | b.lo], [a.hi | b.hi]} (32-lane halves)
+  return __builtin_amdgcn_permlane32_swap(a, b, false, false);
+}
+template <int TYPE, int NPX, int NI, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_qd_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
+                                                          const float* __restrict__ xsum, int tpad, float* __restrict__ y,
+                                                          const float* __restrict__ resid, int T, int mtiles, int ntiles) {
+  constexpr int BN = 32 * NI, NT = 64 * NW, BMD = 32 * NW;
+  constexpr bool PER16 = TYPE == TL_Q6_K;
+  constexpr int XPL = BN * LROW;                   // one plane of one chunk
+  constexpr int XPIECES = 2 * NPX * BN * 4;        // 16-byte pieces of one step's activation tile
+  constexpr int XR = (XPIECES + NT - 1) / NT;      // pieces per thread
+  constexpr size_t BUF_BYTES = (size_t)2 * NPX * XPL * sizeof(__bf16) + 2 * BN * sizeof(float);
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int M = w.rows, K = w.cols;
+  const int tile = blockIdx.x;
+  const int nt = tile / mtiles, mt = tile - nt * mtiles;
+  const int m0 = mt * BMD, n0 = nt * BN;
+  const int ns_all = K / 64, sper = (ns_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int sbase = (int)blockIdx.y * sper;
+  const int ns = ns_all - sbase < sper ? ns_all - sbase : sper;
+  const int nsr = (ns + QD_SETS - 1) / QD_SETS * QD_SETS;  // a multiple of the register-set rotation
+  auto phys = [&](int ss) { return sbase + (ss < ns ? ss : ns - 1); };  // (steps past the end reload the last one)
+  if (gridDim.y > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
+  auto xbuf = [&](int b) { return reinterpret_cast<__bf16*>(lds_raw + (size_t)b * BUF_BYTES); };
+  auto sbuf = [&](int b) { return reinterpret_cast<float*>(lds_raw + (size_t)b * BUF_BYTES + (size_t)2 * NPX * XPL * sizeof(__bf16)); };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int row = m0 + 32 * wave + fr;
+  const size_t R = (size_t)(row < M ? row : M - 1);
+
+  // this thread's pieces of the activation tile: piece = (chunk, plane, token row, quarter). No lane is masked off (a
+  // load in a divergent branch makes hipcc drain the whole prefetch queue at the join): where the pieces do not divide
+  // evenly, the spare threads copy a piece a second time (same bytes to the same LDS address).
+  const __bf16* xg[XR];
+  int xl[XR];
+#pragma unroll
+  for (int r = 0; r < XR; ++r) {
+    const int id = (tid + r * NT) % XPIECES;
+    const int cp = id / (BN * 4), rem = id - cp * (BN * 4), tr = rem >> 2, q = rem & 3;
+    const int c = cp / NPX, p = cp - c * NPX;
+    xg[r] = xp + (size_t)p * plane_stride + (size_t)(n0 + tr) * K + c * 32 + q * 8;
+    xl[r] = cp * XPL + lds_off(tr, q);
+  }
+  const int sxi = tid % (2 * BN);  // block sums of x: [chunk][token]
+  const float* sg = xsum + (size_t)(sxi / BN) * tpad + n0 + sxi % BN;
+  struct XRegs {
+    bf16x8 v[XR];
+    float sx;
+  };
+  auto fetch_x = [&](XRegs& g, int ss) {
+    const int sn = phys(ss);
+#pragma unroll
+    for (int r = 0; r < XR; ++r) g.v[r] = *reinterpret_cast<const bf16x8*>(xg[r] + (size_t)sn * 64);
+    if (TYPE == TL_Q4_K) g.sx = sg[(size_t)(2 * sn) * tpad];
+  };
+  auto write_x = [&](const XRegs& g, int buf) {
+    __bf16* xb = xbuf(buf);
+#pragma unroll
+    for (int r = 0; r < XR; ++r) *reinterpret_cast<bf16x8*>(xb + xl[r]) = g.v[r];
+    if (TYPE == TL_Q4_K) sbuf(buf)[sxi] = g.sx;
+  };
+  struct WRegs {
+    u32x4 q0, q1;  // the payload of chunk 2s + fh (q1: second half of a Q8 chunk)
+    u32x2 hi;      // Q6_K: its high bits
+    u32x4 hdr;     // Q4_K: super-block header; Q6_K: [0] = the four scale bytes of both chunks
+    unsigned d;    // Q6_K / Q8_K: d of the super-block; Q8_0: d of both chunks
+  };
+  auto fetch_w = [&](WRegs& g, int ss) {
+    const int sn = phys(ss);
+    const size_t c0 = (size_t)2 * sn, cm = c0 + fh, cols = (size_t)K;
+    if (TYPE == TL_Q4_K) {
+      g.q0 = *reinterpret_cast<const u32x4*>(w.p0 + R * (cols >> 1) + cm * 16);
+      g.hdr = *reinterpret_cast<const u32x4*>(w.p1 + R * (cols >> 4) + (c0 >> 3) * 16);
+    } else if (TYPE == TL_Q6_K) {
+      g.q0 = *reinterpret_cast<const u32x4*>(w.p0 + R * (cols >> 1) + cm * 16);
+      g.hi = *reinterpret_cast<const u32x2*>(w.p1 + R * (cols >> 2) + cm * 8);
+      g.hdr[0] = *reinterpret_cast<const unsigned*>(w.p2 + R * (cols >> 4) + c0 * 2);
+      g.d = *reinterpret_cast<const uint16_t*>(w.p3 + (R * (cols >> 8) + (c0 >> 3)) * 2);
+    } else {
+      g.q0 = *reinterpret_cast<const u32x4*>(w.p0 + R * cols + cm * 32);
+      g.q1 = *reinterpret_cast<const u32x4*>(w.p0 + R * cols + cm * 32 + 16);
+      if (TYPE == TL_Q8_0) g.d = *reinterpret_cast<const unsigned*>(w.p1 + (R * (cols >> 5) + c0) * 2);
+      else g.d = *reinterpret_cast<const uint16_t*>(w.p1 + (R * (cols >> 8) + (c0 >> 3)) * 2);
+    }
+  };
+
+  f32x16 acc[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](const WRegs& g, int buf, int ss) {
+#pragma clang fp contract(off)
+    const int c0 = 2 * phys(ss);
+    // operands [chunk][16-column half]: quarter 2 * k16 + fh of chunk c0 + chunk in every lane
+    Raw8 op[2][2] = {};
+    if (TYPE == TL_Q4_K || TYPE == TL_Q6_K) {
+      const u32x2 s01 = half_swap(g.q0[0], g.q0[1]), s23 = half_swap(g.q0[2], g.q0[3]);
+      op[0][0].a = s01[0]; op[1][0].a = s01[1];
+      op[0][1].a = s23[0]; op[1][1].a = s23[1];
+      if (TYPE == TL_Q6_K) {
+        const u32x2 h0 = half_swap(g.hi[0], g.hi[0]), h1 = half_swap(g.hi[1], g.hi[1]);
+        op[0][0].b = h0[0]; op[1][0].b = h0[1];
+        op[0][1].b = h1[0]; op[1][1].b = h1[1];
+      }
+    } else {
+      const u32x2 s02 = half_swap(g.q0[0], g.q0[2]), s13 = half_swap(g.q0[1], g.q0[3]);
+      const u32x2 s46 = half_swap(g.q1[0], g.q1[2]), s57 = half_swap(g.q1[1], g.q1[3]);
+      op[0][0].a = s02[0]; op[0][0].b = s13[0]; op[1][0].a = s02[1]; op[1][0].b = s13[1];
+      op[0][1].a = s46[0]; op[0][1].b = s57[0]; op[1][1].a = s46[1]; op[1][1].b = s57[1];
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const __bf16* xb = xbuf(buf) + c * NPX * XPL;
+      float s16[2] = {0.f, 0.f}, m1 = 0.f;
+      if (TYPE == TL_Q4_K) {
+        const int j = (c0 + c) & 7;
+        const float d = h2f(g.hdr[0] & 0xffffu), dmin = h2f(g.hdr[0] >> 16);
+        const unsigned sc = ((g.hdr[1] >> (4 * j)) & 15u) | (((g.hdr[3] >> (2 * j)) & 3u) << 4);
+        const unsigned mn = ((g.hdr[2] >> (4 * j)) & 15u) | (((g.hdr[3] >> (16 + 2 * j)) & 3u) << 4);
+        s16[0] = __fmul_rn(d, (float)sc);
+        m1 = __fmul_rn(dmin, (float)mn);
+      } else if (TYPE == TL_Q6_K) {
+        const float d = h2f(g.d);
+        s16[0] = __fmul_rn(d, (float)(int)(signed char)((g.hdr[0] >> (16 * c)) & 0xffu));
+        s16[1] = __fmul_rn(d, (float)(int)(signed char)((g.hdr[0] >> (16 * c + 8)) & 0xffu));
+      } else if (TYPE == TL_Q8_0) {
+        s16[0] = h2f_scale((g.d >> (16 * c)) & 0xffffu);
+      } else {
+        s16[0] = h2f_scale(g.d);
+      }
+      f32x16 t[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) t[i] = zero;
+#pragma unroll
+      for (int k16 = 0; k16 < 2; ++k16) {
+        const bf16x8 b = unpack8<TYPE>(op[c][k16], 2 * k16 + fh);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+#pragma unroll
+          for (int p = NPX - 1; p >= 0; --p) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(32 * i + fr, k16 * 2 + fh));
+            t[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, t[i], 0, 0, 0);
+          }
+          if (PER16) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = fmaf(s16[k16], t[i][e], acc[i][e]);
+            t[i] = zero;
+          }
+        }
+      }
+      if (!PER16) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][e] = fmaf(s16[0], t[i][e], acc[i][e]);
+      }
+      if (TYPE == TL_Q4_K) {
+        const float* sx = sbuf(buf) + c * BN;
+        const float nsb = -m1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          f32x4 v[4];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(sx + 32 * i + 8 * g4 + 4 * fh);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][e] = fmaf(nsb, v[e >> 2][e & 3], acc[i][e]);
+        }
+      }
+    }
+  };
+
+  // Both prefetch queues live in registers, indexed by unrolled constants only. The activation pieces run three steps
+  // ahead too (an L2 round trip per step would otherwise bound the step time); the LDS image stays double-buffered.
+  static_assert(QD_SETS % 3 == 0, "the unrolled rotation must cover the three activation register sets");
+  WRegs sets[QD_SETS];
+  XRegs xs[3];
+#pragma unroll
+  for (int u = 0; u < QD_SETS; ++u) fetch_w(sets[u], u);
+  fetch_x(xs[0], 0);
+  fetch_x(xs[1], 1);
+  fetch_x(xs[2], 2);
+  write_x(xs[0], 0);
+  fetch_x(xs[0], 3);
+  __syncthreads();
+  for (int ss = 0; ss < nsr; ss += QD_SETS) {
+#pragma unroll
+    for (int u = 0; u < QD_SETS; ++u) {
+      write_x(xs[(u + 1) % 3], (ss + u + 1) & 1);  // step ss+u+1, fetched three iterations ago
+      fetch_x(xs[(u + 1) % 3], ss + u + 4);
+      if (ss + u < ns) compute(sets[u], (ss + u) & 1, ss + u);
+      fetch_w(sets[u], ss + u + QD_SETS);
+      __syncthreads();
+    }
+  }
+  if (row < M) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = n0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (t < T) {
+          const size_t o = (size_t)t * M + row;
+          y[o] = resid ? resid[o] + acc[i][e] : acc[i][e];
+        }
+      }
+  }
+}
+
 // ---- producers of the activation planes ----------------------------------------------------------------------------
 // planes[p][t][k] bf16, t < Tpad (rows >= T are never written: a token row only ever meets its own output row)
 enum SplitMode { SPLIT_PLAIN = 0, SPLIT_RMSNORM = 1, SPLIT_SWIGLU = 2 };
@@ -945,6 +1173,76 @@ int launch_gemm_qi(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
   return launch_gemm_qi_np<TYPE, 3, 64>(w, xp, ps, y, resid, T, s);
 }
 
+// the direct kernel: 32*NI-token tiles, NW waves (32 rows each) per workgroup, K split so that every CU has ~2 workgroups
+template <int TYPE, int NPX, int NI, int NW>
+int launch_gemm_qd_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int S, hipStream_t s) {
+  constexpr int BN = 32 * NI, BMD = 32 * NW;
+  const int mtiles = (w.rows + BMD - 1) / BMD, ntiles = (T + BN - 1) / BN;
+  constexpr size_t lds = 2 * ((size_t)2 * NPX * BN * LROW * sizeof(__bf16) + 2 * BN * sizeof(float));
+  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
+  const int tpad = (int)tl_gemm_padded_tokens(T);
+  const int tiles = mtiles * ntiles;
+  float* part = nullptr;
+  if (S > 1) {
+    const int slot = ksplit_slot(s);
+    if (slot < 0) S = 1;
+    else {
+      void* p = nullptr;
+      TL_TRY(tl_scratch(slot, sizeof(float) * (size_t)S * T * w.rows, &p));
+      part = static_cast<float*>(p);
+    }
+  }
+  if (S == 1) {
+    gemm_qd_kernel<TYPE, NPX, NI, NW><<<dim3(tiles), dim3(64 * NW), lds, s>>>(w, xp, ps, xsum, tpad, y, resid, T, mtiles, ntiles);
+  } else {
+    gemm_qd_kernel<TYPE, NPX, NI, NW><<<dim3(tiles, S), dim3(64 * NW), lds, s>>>(w, xp, ps, xsum, tpad, part, nullptr, T, mtiles, ntiles);
+    const size_t n = (size_t)T * w.rows;
+    ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
+  }
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+template <int TYPE, int NPX, int NI>
+int launch_gemm_qd_ni(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  const int ntiles = (T + 32 * NI - 1) / (32 * NI), nk_all = w.cols / 64, want = 2 * gemm_num_cus();
+  auto slices = [&](int tiles) {
+    int S = 1;
+    if (ksplit_enabled() && tiles < want) {
+      S = (want + tiles - 1) / tiles;
+      if (S > 8) S = 8;
+      if (S > nk_all / 6) S = nk_all / 6;  // at least six 64-column steps per slice
+      if (S < 1) S = 1;
+      const int kper = (nk_all + S - 1) / S;
+      S = (nk_all + kper - 1) / kper;
+    }
+    return S;
+  };
+  // eight waves (256 rows) share a staged activation tile when that still fills the chip, else four
+  const int tiles8 = (w.rows + 255) / 256 * ntiles, tiles4 = (w.rows + 127) / 128 * ntiles;
+  const int S8 = slices(tiles8);
+  if (tiles8 * S8 >= want) return launch_gemm_qd_inst<TYPE, NPX, NI, 8>(w, xp, ps, y, resid, T, S8, s);
+  return launch_gemm_qd_inst<TYPE, NPX, NI, 4>(w, xp, ps, y, resid, T, slices(tiles4), s);
+}
+template <int TYPE>
+int launch_gemm_qd(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms, hipStream_t s) {
+  const bool wide = T > 32 && T <= 64;  // one pass with 64-token tiles, else 32-token tiles
+  if (terms == 3) {
+    return wide ? launch_gemm_qd_ni<TYPE, 2, 2>(w, xp, ps, y, resid, T, s) : launch_gemm_qd_ni<TYPE, 2, 1>(w, xp, ps, y, resid, T, s);
+  }
+  return wide ? launch_gemm_qd_ni<TYPE, 3, 2>(w, xp, ps, y, resid, T, s) : launch_gemm_qd_ni<TYPE, 3, 1>(w, xp, ps, y, resid, T, s);
+}
+// token counts up to which the direct kernel is taken (TL_GEMM_DIRECT: 0 = never)
+static int gemm_direct_max() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TL_GEMM_DIRECT");
+    v = e ? atoi(e) : 32;
+    if (v < 0) v = 0;
+    if (v > 64) v = 64;
+  }
+  return v;
+}
+
 template <int TYPE, int BM>
 int launch_gemm_ws_bm(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms,
                       hipStream_t s) {
@@ -975,6 +1273,7 @@ int launch_gemm_typed(const QW& w, const __bf16* xp, size_t ps, float* y, const 
     ws = v ? atoi(v) : 1;  // default: the wave-specialised kernel; TL_GEMM_WS=0 selects the unified one (A/B runs)
   }
   // (one MFMA per product leaves nothing to save on the matrix cores: the plain bf16 form stays on the dequantizing kernel)
+  if (integer_planes && terms != 1 && T <= gemm_direct_max() && w.cols % 64 == 0) return launch_gemm_qd<TYPE>(w, xp, ps, y, resid, T, terms, s);
   if (integer_planes && terms != 1) return launch_gemm_qi<TYPE>(w, xp, ps, y, resid, T, terms, forced == 64 ? 64 : 128, s);
   const long tiles128 = (long)((w.rows + 127) / 128) * ((T + GB_N - 1) / GB_N);
   if (ws) {  // 128-row tiles halve the LDS fragment traffic per MFMA but leave one workgroup per CU: measured 14 % slower

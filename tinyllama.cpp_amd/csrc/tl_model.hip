@@ -695,7 +695,12 @@ extern "C" int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmu
     if (bytes_per_launch_out) *bytes_per_launch_out = sizeof(float) * (double)m->cfg.hidden_size;
     return tp_check_peer(m);
   }
-  const int L = m->cfg.num_hidden_layers;
+  // TL_BENCH_LAYER_SPAN=n cycles over the first n layers only (1: the weights stay in the 256 MiB Infinity Cache)
+  int L = m->cfg.num_hidden_layers;
+  if (const char* e = getenv("TL_BENCH_LAYER_SPAN")) {
+    const int n = atoi(e);
+    if (n >= 1 && n < L) L = n;
+  }
   auto args_of = [&](int i) {
     const int l = i % L;
     switch (kind) {
@@ -1174,7 +1179,7 @@ static int batch_attn_half(tl_model* m, int l, int T, hipStream_t s) {
   return tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s);
 }
 
-// The same step for a FEW sequences (T <= batch_gemv_max, default 12): the projections as multi-vector GEMVs
+// The same step for a FEW sequences (T <= batch_gemv_max, default 8): the projections as multi-vector GEMVs
 // (gemv_nv_kernel: one pass over the weights for up to four tokens, RMSNorm / residual / SwiGLU fused as in the
 // single-sequence step) instead of matrix-core GEMMs, whose cost per step does not fall below that of 128 tokens.
 static bool batch_gemv_ok(const tl_model* m) {
@@ -1332,7 +1337,7 @@ extern "C" int tl_model_batch_init(tl_model* m, int max_batch) {
   TL_HIP(hipMalloc(&b.seq, sizeof(int) * kPrefillChunk));
   TL_HIP(hipMalloc(&b.last_h, sizeof(float) * (size_t)max_batch * m->cfg.hidden_size));
   b.max_batch = max_batch;
-  b.gemv_max = batch_gemv_ok(m) ? 12 : 0;  // three passes of four vectors still beat the 128-token GEMM step
+  b.gemv_max = batch_gemv_ok(m) ? 8 : 0;  // two passes of four vectors cost what one step of the direct small-token GEMM does
   if (const char* e = getenv("TL_BATCH_GEMV_MAX")) {  // A/B runs: 0 = always the matrix-core GEMMs
     const int v = atoi(e);
     if (v >= 0 && v <= 64 && b.gemv_max) b.gemv_max = v;

@@ -69,6 +69,46 @@ def test_gemm_vs_oracle(E, pkg, oracle, name, rows, cols, T):
 
 
 @pytest.mark.parametrize("name,rows,cols,T", [
+    ("q4_k", 333, 4096, 9), ("q4_k", 1024, 14336, 12), ("q6_k", 257, 1024, 32), ("q6_k", 4100, 4096, 40),
+    ("q8_0", 100, 192, 17), ("q8_k", 130, 768, 20), ("q4_k", 96, 256, 64), ("q8_0", 2048, 2048, 50)])
+def test_direct_small_token_gemm(E, pkg, oracle, monkeypatch, name, rows, cols, T):
+    """gemm_qd_kernel (weights from global memory straight into the MFMA operand; launches of at most 32 tokens by
+    default, 64 with TL_GEMM_DIRECT=64): every format, row counts off the 32-row fragments, K splits with many and with
+    a single 64-column step, 32- and 64-token tiles -- against the oracle at the GEMM bars, and against the
+    integer-plane kernel it stands in for (TL_GEMM_DIRECT=0): same factorisation, so FP32 rounding apart."""
+    from tinyllama_cpp_amd.capi import lib, check
+    t, S = TYPES[name], pkg.synth
+    rng = np.random.default_rng(7 * rows + cols + T)
+    blocks = S.random_blocks(t, rows * cols // S.BLOCK_ELEMS[t], rng, w_std=1.0 / np.sqrt(cols))
+    x = rng.standard_normal((T, cols)).astype(np.float32)
+    sc = np.ones((T, 1), np.float32)
+    sc[0], sc[-1] = 2.0 ** -10, 64.0
+    x *= sc
+    want = oracle.matmul_q_batch(t, blocks, x, T, rows, cols)
+    w = E.QWeight(t, blocks, rows, cols)
+    rowmax = np.maximum(sc, np.abs(want).max(axis=1, keepdims=True))
+    out = {}
+    for direct in ("64", "0"):
+        monkeypatch.setenv("TL_GEMM_DIRECT", direct)
+        for terms in (6, 3):
+            check(lib().tl_gemm_set_terms(terms))
+            y = _matmul(E, w, x)
+            out[direct, terms] = y
+            if terms == 6:
+                assert close(y / sc, want / sc, TOL[6]).all(), (direct, np.abs(y / sc - want / sc).max())
+            else:
+                assert (np.abs(y - want) <= TOL[3] * rowmax).all(), (direct, (np.abs(y - want) / rowmax).max())
+    check(lib().tl_gemm_set_terms(6))
+    assert (np.abs(out["64", 6] - out["0", 6]) <= 2e-5 * rowmax).all()
+    monkeypatch.setenv("TL_GEMM_DIRECT", "64")
+    perm = rng.permutation(T)
+    assert np.array_equal(_matmul(E, w, x[perm]), out["64", 6][perm])
+    if T <= 32:  # the default limit takes the same kernel as the explicit one
+        monkeypatch.delenv("TL_GEMM_DIRECT")
+        assert np.array_equal(_matmul(E, w, x), out["64", 6])
+
+
+@pytest.mark.parametrize("name,rows,cols,T", [
     ("q4_k", 4096, 4096, 2), ("q4_k", 333, 1024, 3), ("q4_k", 1024, 14336, 5), ("q6_k", 257, 4096, 4),
     ("q6_k", 64, 14336, 7), ("q8_0", 1000, 2048, 6), ("q8_0", 33, 32, 2), ("q8_k", 128, 768, 3), ("q4_k", 1, 256, 7)])
 def test_few_tokens_take_the_multi_vector_gemv(E, pkg, oracle, name, rows, cols, T):

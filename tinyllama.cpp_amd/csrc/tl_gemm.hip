@@ -1231,16 +1231,12 @@ int launch_gemm_qd(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
   }
   return wide ? launch_gemm_qd_ni<TYPE, 3, 2>(w, xp, ps, y, resid, T, s) : launch_gemm_qd_ni<TYPE, 3, 1>(w, xp, ps, y, resid, T, s);
 }
-// token counts up to which the direct kernel is taken (TL_GEMM_DIRECT: 0 = never)
+// token counts up to which the direct kernel is taken (TL_GEMM_DIRECT: 0 = never, at most 64; read at every launch so
+// that one process can compare the routes)
 static int gemm_direct_max() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("TL_GEMM_DIRECT");
-    v = e ? atoi(e) : 32;
-    if (v < 0) v = 0;
-    if (v > 64) v = 64;
-  }
-  return v;
+  const char* e = getenv("TL_GEMM_DIRECT");
+  const int v = e ? atoi(e) : 32;
+  return v < 0 ? 0 : (v > 64 ? 64 : v);
 }
 
 template <int TYPE, int BM>

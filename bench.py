@@ -136,7 +136,21 @@ def main():
                     dist.all_reduce(t, op=dist.ReduceOp.MIN)
                     return bool(int(t.item()))
 
-                linked = pkg_tp.peer_link(model, gather, agree)
+                # Pre-flight: link + self-check + a short run of the exchange in THROW-AWAY child processes first, one per
+                # rank on this rank's GPU (tools/peer_latency.py worker). The exchange has only ever run between
+                # processes on one GPU; should the mapped areas fault over real links, that costs a child, not the bench:
+                # every rank then stays on RCCL.
+                import subprocess
+                import tempfile
+                box = [tempfile.mkdtemp(prefix="tl_peer_") if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                cmd = [sys.executable, "-u", os.path.join(ROOT, "tools", "peer_latency.py"), "--worker", str(tp_rank),
+                       str(tp_size), "--iters", "50", "--dir", box[0], "--device", str(local), "--rv-timeout", "30"]
+                try:
+                    pre_ok = subprocess.run(cmd, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+                except Exception:
+                    pre_ok = False
+                linked = agree(pre_ok) and pkg_tp.peer_link(model, gather, agree)
                 if SHARE_GPU and not linked:
                     raise RuntimeError("ranks sharing one GPU can only be linked by the peer exchange, which was refused: "
                                        + engine.lib().tl_last_error().decode(errors="replace"))

@@ -16,19 +16,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def worker(rank, tp_size, hidden, iters, workdir):
+def worker(rank, tp_size, hidden, iters, workdir, device=0, rv_timeout=120.0):
     from _pkg import load_package
     pkg = load_package()
     S = pkg.synth
     from tinyllama_cpp_amd import engine as E
     from tinyllama_cpp_amd import tp
-    E.init(0)
+    E.init(device)
     heads = hidden // 128
     cfg = dict(S.SHAPES["llama-3-8b"], hidden=hidden, n_heads=heads, n_kv_heads=8, inter=512 * tp_size, n_layers=1,
                vocab=1024 * tp_size, max_pos=64)
     cfg, tensors = S.build_model(cfg, "q4_k_m", seed=1)
     m = E.Model(cfg, tp_rank=rank, tp_size=tp_size)
-    rv = tp.FileRendezvous(workdir, rank, tp_size)
+    rv = tp.FileRendezvous(workdir, rank, tp_size, timeout=rv_timeout)
     if not tp.peer_link(m, rv.gather, rv.agree):
         print(f"rank {rank}: not linked: {E.lib().tl_last_error().decode(errors='replace')}")
         return 3
@@ -51,9 +51,11 @@ def main():
     ap.add_argument("--iters", type=int, default=2000)
     ap.add_argument("--worker", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--dir", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--device", type=int, default=0, help=argparse.SUPPRESS)  # bench.py's pre-flight: this rank's own GPU
+    ap.add_argument("--rv-timeout", type=float, default=120.0, help=argparse.SUPPRESS)
     a = ap.parse_args()
     if a.worker:
-        return worker(a.worker[0], a.worker[1], a.hidden, a.iters, a.dir)
+        return worker(a.worker[0], a.worker[1], a.hidden, a.iters, a.dir, a.device, a.rv_timeout)
     rc = 0
     for tp_size in a.tp:
         with tempfile.TemporaryDirectory() as d:

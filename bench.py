@@ -227,7 +227,7 @@ def main():
     # ---- the dominant kernel (fused RMSNorm + ffn_gate/ffn_up GEMV + SwiGLU): average launch duration with HIP events
     #      on the engine's stream, back-to-back launches cycling through the layers (every launch streams from HBM);
     #      algorithmic bytes = GGUF bytes of the two matrices one launch reads --------------------------
-    gu_us, gu_bytes = model.bench_kernel("gate_up_gemv", iters=8 * cfg["n_layers"], warmup=cfg["n_layers"])
+    gu_us, gu_bytes = model.bench_kernel("gate_up_gemv", iters=8 * cfg["n_layers"], warmup=8 * cfg["n_layers"])  # (the clocks settle during the warm-up)
     achieved = gu_bytes / (gu_us * 1e-6) / 1e9 if gu_us > 0 else 0.0
     kern = {}
     for k in ("qkv_gemv", "attn_out_gemv", "gate_up_gemv", "down_gemv", "lm_head_gemv"):

@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--batch-seqs", type=int, default=128, help="sequences of the multi-sequence decode leg")
     ap.add_argument("--prompt-len", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-layers", type=int, default=2, help="layers in the CPU-baseline sample")
+    ap.add_argument("--cpu-layers", type=int, default=8, help="layers in the CPU-baseline sample")
     return ap.parse_args()
 
 

@@ -223,7 +223,7 @@ struct GemvVec {
   const float* resid;
   float eps;
   int cols;
-  unsigned long long* stamps;  // diagnostic instantiation only: 8 shader-clock stamps per wave
+  unsigned long long* stamps;  // diagnostic instantiation only: 10 u64 per wave (tl_debug_gemv_stamps)
   // GEMV_ATTN_OUT_COMBINE: x is the attention output still in split partials (tl_attn.hip), combined while staging
   const float* attn_ws;
   const int* attn_pos;
@@ -448,9 +448,9 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   const int nchunks = a.cols >> 5;
   const int nspans = (nchunks + 63) >> 6;
   if (first >= total) {  // a wave without work only helps staging x
-    if (STAMP) ts[1] = __builtin_readcyclecounter();
+    if (STAMP) ts[3] = __builtin_readcyclecounter();
     stage_x_finish<XATTN>(a, xr, smem);
-    if (STAMP) ts[2] = __builtin_readcyclecounter();
+    if (STAMP) ts[4] = __builtin_readcyclecounter();
     return;
   }
   int irg = first, isp = 0;
@@ -517,18 +517,19 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   Step<TYPE> cur, nxt;
   StepMeta mc, mn;
   issue(cur, mc);  // the first step's loads go out before x is staged: the HBM round trip overlaps the prologue
-  if (STAMP) ts[1] = __builtin_readcyclecounter();
+  if (STAMP) ts[3] = __builtin_readcyclecounter();
   stage_x_finish<XATTN>(a, xr, smem);
-  if (STAMP) ts[2] = __builtin_readcyclecounter();
+  if (STAMP) ts[4] = __builtin_readcyclecounter();
   while (irg < total) {
     issue(nxt, mn);
     consume(cur, mc);
-    if (STAMP && ts[3] == 0) ts[3] = __builtin_readcyclecounter();
+    if (STAMP && ts[5] == 0) ts[5] = __builtin_readcyclecounter();
     cur = nxt;
     mc = mn;
   }
+  if (STAMP) ts[6] = __builtin_readcyclecounter();  // every load of this wave has been issued
   consume(cur, mc);
-  if (STAMP && ts[3] == 0) ts[3] = __builtin_readcyclecounter();
+  if (STAMP && ts[5] == 0) ts[5] = __builtin_readcyclecounter();
 }
 
 
@@ -707,7 +708,7 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
   constexpr bool RESID = ROLE == GEMV_ATTN_OUT || ROLE == GEMV_DOWN || ROLE == GEMV_ATTN_OUT_COMBINE;
   constexpr bool XATTN = ROLE == GEMV_ATTN_OUT_COMBINE;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  unsigned long long ts[5] = {0, 0, 0, 0, 0}, rt0 = 0;
+  unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0 = 0;
   if (STAMP) {
     ts[0] = __builtin_readcyclecounter();
     rt0 = __builtin_amdgcn_s_memrealtime();
@@ -722,11 +723,16 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
     asm volatile("" ::"s"(sg1.w.p0), "s"(sg1.w.p1), "s"(sg1.w.p2), "s"(sg1.w.p3), "s"(sg1.w.rows), "s"(sg1.out));
   if (ROLE == GEMV_QKV)
     asm volatile("" ::"s"(sg2.w.p0), "s"(sg2.w.p1), "s"(sg2.w.p2), "s"(sg2.w.p3), "s"(sg2.w.rows), "s"(sg2.out));
+  if (STAMP) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the arguments have arrived
+    ts[1] = __builtin_readcyclecounter();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = blockDim.x >> 6;
   XRegs xr;
   stage_x_issue<XATTN>(a, xr);
+  if (STAMP) ts[2] = __builtin_readcyclecounter();
   if (TB == TL_NONE || wave < wavesA) {
     const int wA = TB == TL_NONE ? nwaves : wavesA;
     const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
@@ -747,12 +753,12 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
       run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
                                                  gridDim.x * (nwaves - wavesA), tb, lane, ts);
   }
-  if (STAMP && lane == 0 && ts[3] != 0) {
-    ts[4] = __builtin_readcyclecounter();
-    unsigned long long* o = a.stamps + 8 * (size_t)(wave * gridDim.x + blockIdx.x);
-    for (int i = 0; i < 5; ++i) o[i] = ts[i];
-    o[5] = __builtin_amdgcn_s_memrealtime();
-    o[6] = rt0;
+  if (STAMP && lane == 0 && ts[5] != 0) {
+    ts[7] = __builtin_readcyclecounter();
+    unsigned long long* o = a.stamps + 10 * (size_t)(wave * gridDim.x + blockIdx.x);
+    for (int i = 0; i < 8; ++i) o[i] = ts[i];
+    o[8] = __builtin_amdgcn_s_memrealtime();
+    o[9] = rt0;
   }
 }
 
@@ -1013,9 +1019,9 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
 }
 
 // Diagnostic hook (no counterpart in the reference): one tl_matvec_q-shaped launch of the stamped instantiation;
-// stamps_dev receives 8 u64 per wave slot (grid * waves-per-block slots, <= 256 * 16): shader-clock stamps at kernel
-// entry, after the first loads were issued, after x staging, after the first step, at wave end; [5], [6] = realtime
-// at wave end / entry. Q4_K and Q6_K only.
+// stamps_dev receives 10 u64 per wave slot (grid * waves-per-block slots, <= 256 * 16): shader-clock stamps at kernel
+// entry, arguments in SGPRs, x loads issued, first weight loads issued, x staged, first step done, last loads issued,
+// wave end (last dot, reduction and store done); [8], [9] = realtime at wave end / entry. Q4_K and Q6_K only.
 extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, unsigned long long* stamps_dev,
                                     int* grid_out, int* waves_out, void* stream) {
   TL_REQUIRE(w && x_dev && y_dev && stamps_dev && (w->type == TL_Q4_K || w->type == TL_Q6_K),
@@ -1030,7 +1036,7 @@ extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, flo
   L.t[0] = (w->rows + 1) / 2;
   L.nsegA = 1;
   L.wavesA = gemv_geometry(L, L.t[0]);
-  TL_HIP(hipMemsetAsync(stamps_dev, 0, sizeof(unsigned long long) * 8 * (size_t)L.grid * (L.threads / 64), s));
+  TL_HIP(hipMemsetAsync(stamps_dev, 0, sizeof(unsigned long long) * 10 * (size_t)L.grid * (L.threads / 64), s));
   if (w->type == TL_Q4_K) TL_TRY((gemv_launch_one<TL_Q4_K, TL_NONE, false, GEMV_GENERIC, true>(L, s)));
   else TL_TRY((gemv_launch_one<TL_Q6_K, TL_NONE, false, GEMV_GENERIC, true>(L, s)));
   TL_HIP(hipGetLastError());

@@ -109,6 +109,16 @@ int tl_update_kv_cache_batch(float* cache_base_dev, const float* kv_batch_dev, i
 int tl_attention(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev, float* out_dev,
                  int num_heads, int current_seq_len, int head_dim, float scale, int cache_max_seq_len,
                  int cache_num_kv_heads, void* stream);
+/* tl_attention for callers that cannot allocate. No counterpart in the reference: it is for code under HIP graph
+ * capture, tight serving loops and harnesses that forbid hipMalloc, where tl_attention's lazily grown workspace is not
+ * an option. Same arguments, same kernels and bit-identical results; the split partials live in a static device array
+ * of 64 heads x 32 splits x (128 + 4) floats (1.03 MiB, held by every GPU the library runs on until the process ends).
+ * Calls hipMalloc / hipFree never; needs tl_init(device) to have run for the current device (it looks up that
+ * device's copy of the array); rejects num_heads * (head_dim + 4) beyond 64 * 132 with an error. All calls on one GPU
+ * share the array: calls that overlap on one GPU (two streams) race. */
+int tl_attention_noalloc(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev, float* out_dev,
+                         int num_heads, int current_seq_len, int head_dim, float scale, int cache_max_seq_len,
+                         int cache_num_kv_heads, void* stream);
 /* sample_top_k_top_p_temperature (api.cpp:126-216) as a device operator (the reference only has it on the host):
  * logits_dev[n] is not modified; u in [0,1) is the caller's uniform variate; *id_dev = the drawn id; optional outputs
  * (NULL to skip): the candidate ids and renormalised probabilities in draw order (capacity >= min(top_k, n)) and their
@@ -192,7 +202,7 @@ int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, flo
 int tl_bench_matvec_prefetch(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int reps,
                              int prefetch_blocks, float* avg_us_out);
 /* Diagnostic hook (no counterpart in the reference): one tl_matvec_q-shaped launch of an instrumented build of the
- * GEMV kernel; stamps_dev[8 * grid * waves] u64 receives per-wave shader-clock stamps (see tl_gemv.hip). */
+ * GEMV kernel; stamps_dev[10 * grid * waves] u64 receives per-wave shader-clock stamps (see tl_gemv.hip). */
 int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, unsigned long long* stamps_dev,
                          int* grid_out, int* waves_out, void* stream);
 /* Measurement hook (no counterpart in the reference): runs n_steps greedy decode steps EAGERLY (no graph) on the

@@ -56,6 +56,7 @@ SIGNATURES = {
     "tl_update_kv_cache": [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "tl_update_kv_cache_batch": [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp],
     "tl_attention": [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _vp],
+    "tl_attention_noalloc": [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, _vp],
     "tl_attention_batch_prefill": [_fp, _fp, _fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, _vp],
     "tl_add_residual": [_fp, _fp, _fp, _sz, _vp],

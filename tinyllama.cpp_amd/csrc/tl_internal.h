@@ -39,6 +39,8 @@ enum TlScratchSlot {
   TL_SCRATCH_GEMM_PART7 = TL_SCRATCH_GEMM_PART0 + 7
 };
 int tl_scratch(int slot, size_t bytes, void** out);
+// tl_ops.hip: looks up the device address of tl_attention_noalloc's static workspace (called by tl_init, device current)
+int tl_ops_init_device(int dev);
 
 // ---- device layout of one quantized matrix -----------------------------------------------------------
 // The GGUF blocks (quantization.h:57-124) are split at upload into 16-byte-aligned planes, row-major by

@@ -329,6 +329,65 @@ extern "C" int tl_attention(const float* q_dev, const float* k_cache_dev, const 
                                current_seq_len, nullptr, cache_max_seq_len, scale, static_cast<hipStream_t>(stream));
 }
 
+// ---- tl_attention for callers that cannot allocate ------------------------------------------------------------------
+// tl_attention keeps its split partials in a lazily grown hipMalloc workspace (tl_scratch), which rules it out under
+// HIP graph capture, in serving loops and in harnesses that forbid allocation. tl_attention_noalloc runs the same two
+// kernels over a file-scope device array instead. The array's name is only a host-side stand-in: its device address is
+// looked up once per device (tl_ops_init_device, called by tl_init with that device current) and only that pointer is
+// ever handed to a kernel.
+constexpr int TL_NOALLOC_MAX_HEADS = 64, TL_NOALLOC_MAX_HEAD_DIM = 128, TL_NOALLOC_MAX_DEVICES = 64;
+constexpr size_t TL_NOALLOC_FLOATS =
+    (size_t)TL_NOALLOC_MAX_HEADS * TL_ATTN_MAX_SPLITS * (TL_NOALLOC_MAX_HEAD_DIM + 4);  // 270,336 floats = 1.03 MiB per GPU
+static __device__ __align__(256) float scratch[TL_NOALLOC_FLOATS];
+static float* g_noalloc_ptr[TL_NOALLOC_MAX_DEVICES] = {};  // per device: each GPU holds its own copy at its own address
+
+int tl_ops_init_device(int dev) {
+  TL_REQUIRE(dev >= 0 && dev < TL_NOALLOC_MAX_DEVICES, "tl_init: device ordinal %d beyond the %d this library tracks", dev,
+             TL_NOALLOC_MAX_DEVICES);
+  if (g_noalloc_ptr[dev]) return 0;
+  float* p = nullptr;
+  TL_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch)));
+  TL_REQUIRE(p, "tl_init: the static workspace has no address on device %d", dev);
+  g_noalloc_ptr[dev] = p;
+  return 0;
+}
+
+extern "C" int tl_attention_noalloc(const float* q_dev, const float* k_cache_dev, const float* v_cache_dev, float* out_dev,
+                                    int num_heads, int current_seq_len, int head_dim, float scale, int cache_max_seq_len,
+                                    int cache_num_kv_heads, void* stream) {
+  TL_REQUIRE(q_dev && k_cache_dev && v_cache_dev && out_dev, "tl_attention_noalloc: null argument");
+  TL_REQUIRE(current_seq_len > 0 && current_seq_len <= cache_max_seq_len, "tl_attention_noalloc: seq_len %d outside (0,%d]",
+             current_seq_len, cache_max_seq_len);
+  if (!tl_attn_split_supported(num_heads, cache_num_kv_heads, head_dim))  // the single-pass kernel needs no workspace
+    return tl_launch_attn_decode(q_dev, k_cache_dev, v_cache_dev, out_dev, num_heads, cache_num_kv_heads, head_dim,
+                                 current_seq_len, nullptr, cache_max_seq_len, scale, static_cast<hipStream_t>(stream));
+  TL_REQUIRE(tl_attn_ws_floats(num_heads, head_dim) <= TL_NOALLOC_FLOATS,
+             "tl_attention_noalloc: %d heads x head_dim %d need %zu floats of partials, the static workspace holds %zu "
+             "(at most %d heads of head_dim %d); use tl_attention",
+             num_heads, head_dim, tl_attn_ws_floats(num_heads, head_dim), TL_NOALLOC_FLOATS, TL_NOALLOC_MAX_HEADS,
+             TL_NOALLOC_MAX_HEAD_DIM);
+  int dev = 0;
+  TL_HIP(hipGetDevice(&dev));
+  TL_REQUIRE(dev >= 0 && dev < TL_NOALLOC_MAX_DEVICES && g_noalloc_ptr[dev],
+             "tl_attention_noalloc: call tl_init(%d) first (it looks up this device's static workspace)", dev);
+  // every split below the active count writes its whole record before the combine reads it, and the combine reads no
+  // other record: nothing left by an earlier call is ever read, so nothing needs clearing
+  AttnArgs a = {};
+  a.q = q_dev;
+  a.kc = const_cast<float*>(k_cache_dev);
+  a.vc = const_cast<float*>(v_cache_dev);
+  a.out = out_dev;
+  a.ws = g_noalloc_ptr[dev];
+  a.nh = num_heads;
+  a.nkv = cache_num_kv_heads;
+  a.hd = head_dim;
+  a.seq_len = current_seq_len;
+  a.max_seq = cache_max_seq_len;
+  a.scale = scale;
+  TL_TRY(tl_launch_attn_split(a, false, static_cast<hipStream_t>(stream)));
+  return tl_launch_attn_combine(a, static_cast<hipStream_t>(stream));
+}
+
 // ---- prefill attention (cpu_attention.cpp:91-201): one workgroup per (token, head), causal via the cache ---
 __global__ __launch_bounds__(256) void attn_prefill_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                            const float* __restrict__ vc, float* __restrict__ out,

@@ -36,7 +36,7 @@ extern "C" int tl_init(int device_ordinal) {
   TL_HIP(hipGetDeviceProperties(&prop, device_ordinal));
   TL_REQUIRE(prop.warpSize == 64, "tl_init: wavefront size %d, kernels are written for wave64 (gfx950)", prop.warpSize);
   TL_HIP(hipFree(nullptr));  // force context creation here rather than inside the first timed call
-  return 0;
+  return tl_ops_init_device(device_ordinal);
 }
 
 extern "C" int tl_malloc(void** dev_out, size_t bytes) {

@@ -201,6 +201,11 @@ int tl_bench_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, flo
  * (prefetch_blocks workgroups of 256 threads; 0 = no prefetch branch, same graph otherwise). */
 int tl_bench_matvec_prefetch(const tl_qweight* const* ws, int nw, const float* x_dev, float* y_dev, int reps,
                              int prefetch_blocks, float* avg_us_out);
+/* Measurement / parity hook (no counterpart in the reference): y_i = W_i x through the ring-loader engine (tl_stream.hip),
+ * the nw equally shaped matrices as nw phases of ONE persistent launch (ys_dev: [nw][rows]); avg_us_out (may be NULL) =
+ * microseconds per matrix over `reps` launches. */
+int tl_stream_matvec(const tl_qweight* const* ws, int nw, const float* x_dev, float* ys_dev, int reps, float* avg_us_out,
+                     void* stream);
 /* Diagnostic hook (no counterpart in the reference): one tl_matvec_q-shaped launch of an instrumented build of the
  * GEMV kernel; stamps_dev[10 * grid * waves] u64 receives per-wave shader-clock stamps (see tl_gemv.hip). */
 int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, float* y_dev, unsigned long long* stamps_dev,

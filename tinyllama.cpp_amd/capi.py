@@ -79,6 +79,7 @@ SIGNATURES = {
     "tl_gemm_set_terms": [C.c_int],
     "tl_bench_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), _vp],
     "tl_bench_matvec_prefetch": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float)],
+    "tl_stream_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.POINTER(C.c_float), _vp],
     "tl_debug_gemv_stamps": [_vp, _fp, _fp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp],
     "tl_model_profile_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "tl_model_bench_kernel": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)],

@@ -199,7 +199,8 @@ extern "C" int tl_qweight_upload(int type, const void* host_blocks, int rows, in
   TL_REQUIRE(rows > 0 && cols > 0, "tl_qweight_upload: bad shape %d x %d", rows, cols);
   tl_qweight* w = new tl_qweight();
   w->bytes = tl_qweight_device_bytes(type, rows, cols);
-  hipError_t e = hipMalloc(&w->base, w->bytes);
+  // (+ 256: the ring-loader engine's 16-byte LDS-DMA lanes may read a few bytes past the last plane, tl_stream.hip)
+  hipError_t e = hipMalloc(&w->base, w->bytes + 256);
   if (e != hipSuccess) {
     delete w;
     tl_set_error("tl_qweight_upload: hipMalloc(%zu) failed: %s", w->bytes, hipGetErrorString(e));

@@ -199,8 +199,8 @@ extern "C" int tl_qweight_upload(int type, const void* host_blocks, int rows, in
   TL_REQUIRE(rows > 0 && cols > 0, "tl_qweight_upload: bad shape %d x %d", rows, cols);
   tl_qweight* w = new tl_qweight();
   w->bytes = tl_qweight_device_bytes(type, rows, cols);
-  // (+ 256: the ring-loader engine's 16-byte LDS-DMA lanes may read a few bytes past the last plane, tl_stream.hip)
-  hipError_t e = hipMalloc(&w->base, w->bytes + 256);
+  // (+ 1280: the ring-loader engine copies whole KiB; the last one of the last plane may read up to 1 KiB past it, tl_stream.hip)
+  hipError_t e = hipMalloc(&w->base, w->bytes + 1280);
   if (e != hipSuccess) {
     delete w;
     tl_set_error("tl_qweight_upload: hipMalloc(%zu) failed: %s", w->bytes, hipGetErrorString(e));

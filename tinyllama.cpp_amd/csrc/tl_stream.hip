@@ -17,6 +17,7 @@
 //     prologue (the loader never joins one).
 // The chunk arithmetic is tl_chunk.h's, so every row is computed exactly as the launch-per-projection GEMV computes it up
 // to the order in which the span partials are added.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "tl_chunk.h"
@@ -24,7 +25,9 @@
 namespace {
 
 constexpr int NCONS = 8;                      // consumer waves
-constexpr int NTHREADS = (NCONS + 1) * 64;    // + the loader wave
+constexpr int NLOAD = 2;                      // loader waves: a wave counts at most 63 copies in flight (63 KiB), two hold
+                                              // what the memory latency needs; loader j copies the items seq % NLOAD == j
+constexpr int NTHREADS = (NCONS + NLOAD) * 64;
 constexpr int RING_BYTES = 128 * 1024;        // weight ring: items of 8-20 KiB, placed back to back (1-KiB granules)
 constexpr int ITEM_MAX_BYTES = 20 * 1024;
 constexpr int NCTRL = 32;                     // control entries, indexed by item sequence number
@@ -60,10 +63,11 @@ struct PhaseDesc {
 struct Ctrl {  // LDS control block behind the ring
   unsigned full[NCTRL];    // sequence number + 1 of the item that has landed
   unsigned done[NCTRL];    // NCONS arrivals per use of the entry: every consumer has read its units and stored its partials
-  unsigned start[NCTRL];   // loader-private: ring offset of the item
+  unsigned start[NLOAD][NCTRL];  // private to each loader: ring offset of every item (its own view of the ring)
   unsigned fail;           // a spin ran out
   unsigned pad[3];
   float partial[NCTRL][MAX_UNITS];  // [entry][unit row * nspans + span]
+  unsigned long long stamps[128][8];  // diagnostic: per-item shader-clock stamps (dumped by workgroup 0 when asked for)
 };
 
 // per-format plane geometry: bytes per row of plane p for `cols` columns (0: no such plane)
@@ -104,7 +108,7 @@ __device__ __forceinline__ bool lds_wait_eq(const unsigned* p, unsigned want, Ct
       lds_st(&c->fail, 1u);
       return false;
     }
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(2);
   }
 }
 
@@ -120,35 +124,154 @@ __device__ __forceinline__ void dma_1k(const uint8_t* gsrc, unsigned lds_dst) {
       "global_load_lds_dwordx4 %1, off nt\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
+      : "v"(gsrc), "s"(__builtin_amdgcn_readfirstlane(lds_dst))
       : "memory");
 }
-
-#define TL_VMCNT_CASE(n) \
-  case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
-// waits until at most n (wave-uniform, 0..63) of this wave's vector-memory operations are outstanding
-__device__ __forceinline__ void wait_vmcnt(unsigned n) {
-  switch (n) {
-    TL_VMCNT_CASE(0) TL_VMCNT_CASE(1) TL_VMCNT_CASE(2) TL_VMCNT_CASE(3) TL_VMCNT_CASE(4) TL_VMCNT_CASE(5) TL_VMCNT_CASE(6)
-    TL_VMCNT_CASE(7) TL_VMCNT_CASE(8) TL_VMCNT_CASE(9) TL_VMCNT_CASE(10) TL_VMCNT_CASE(11) TL_VMCNT_CASE(12)
-    TL_VMCNT_CASE(13) TL_VMCNT_CASE(14) TL_VMCNT_CASE(15) TL_VMCNT_CASE(16) TL_VMCNT_CASE(17) TL_VMCNT_CASE(18)
-    TL_VMCNT_CASE(19) TL_VMCNT_CASE(20) TL_VMCNT_CASE(21) TL_VMCNT_CASE(22) TL_VMCNT_CASE(23) TL_VMCNT_CASE(24)
-    TL_VMCNT_CASE(25) TL_VMCNT_CASE(26) TL_VMCNT_CASE(27) TL_VMCNT_CASE(28) TL_VMCNT_CASE(29) TL_VMCNT_CASE(30)
-    TL_VMCNT_CASE(31) TL_VMCNT_CASE(32) TL_VMCNT_CASE(33) TL_VMCNT_CASE(34) TL_VMCNT_CASE(35) TL_VMCNT_CASE(36)
-    TL_VMCNT_CASE(37) TL_VMCNT_CASE(38) TL_VMCNT_CASE(39) TL_VMCNT_CASE(40) TL_VMCNT_CASE(41) TL_VMCNT_CASE(42)
-    TL_VMCNT_CASE(43) TL_VMCNT_CASE(44) TL_VMCNT_CASE(45) TL_VMCNT_CASE(46) TL_VMCNT_CASE(47) TL_VMCNT_CASE(48)
-    TL_VMCNT_CASE(49) TL_VMCNT_CASE(50) TL_VMCNT_CASE(51) TL_VMCNT_CASE(52) TL_VMCNT_CASE(53) TL_VMCNT_CASE(54)
-    TL_VMCNT_CASE(55) TL_VMCNT_CASE(56) TL_VMCNT_CASE(57) TL_VMCNT_CASE(58) TL_VMCNT_CASE(59) TL_VMCNT_CASE(60)
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+// N consecutive KiB from a WAVE-UNIFORM global base (SGPR pair) + this lane's fixed offset lane * 16 (one VGPR, set once)
+// with ONE M0: the instruction's immediate offset moves the global and the LDS address alike. No vector arithmetic per
+// copy: the loader's whole item loop runs on the scalar unit.
+template <int N>
+__device__ __forceinline__ void dma_nk(const uint8_t* sbase, unsigned lane16, unsigned lds_dst) {
+  static_assert(N >= 1 && N <= 4, "immediate offsets reach 3 KiB");
+  unsigned keep;
+  const unsigned long long sb = (unsigned long long)sbase;
+  const unsigned d = __builtin_amdgcn_readfirstlane(lds_dst);
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(d), "s"(sb) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(d), "s"(sb) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(d), "s"(sb) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %3 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:1024 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:2048 nt\n\t"
+                 "global_load_lds_dwordx4 %1, %3 offset:3072 nt\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane16), "s"(d), "s"(sb) : "memory");
+}
+// `ni` whole KiB from the wave-uniform base to LDS lds_dst
+__device__ __forceinline__ void dma_run(const uint8_t* sbase, unsigned lane16, unsigned lds_dst, int ni) {
+  for (; ni >= 4; ni -= 4) {
+    dma_nk<4>(sbase, lane16, lds_dst);
+    sbase += 4096;
+    lds_dst += 4096u;
   }
+  if (ni == 3) dma_nk<3>(sbase, lane16, lds_dst);
+  else if (ni == 2) dma_nk<2>(sbase, lane16, lds_dst);
+  else if (ni == 1) dma_nk<1>(sbase, lane16, lds_dst);
 }
 
+// waits until at most n & ~3 (n wave-uniform, 0..63) of this wave's vector-memory operations are outstanding: rounding
+// down only waits for a few loads more. One hand-written branch tree (four bit tests on the way to the wait): a C++
+// switch over 61 immediates became a structurised chain of ~50 branches per call.
+__device__ __forceinline__ void wait_vmcnt(unsigned n) {
+  asm volatile(
+      "s_bitcmp1_b32 %0, 5\n\t"
+      "s_cbranch_scc1 11f\n\t"
+      "s_bitcmp1_b32 %0, 4\n\t"
+      "s_cbranch_scc1 12f\n\t"
+      "s_bitcmp1_b32 %0, 3\n\t"
+      "s_cbranch_scc1 13f\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 14f\n\t"
+      "s_waitcnt vmcnt(0)\n\t"
+      "s_branch 9f\n\t"
+      "14:\n\t"
+      "s_waitcnt vmcnt(4)\n\t"
+      "s_branch 9f\n\t"
+      "13:\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 15f\n\t"
+      "s_waitcnt vmcnt(8)\n\t"
+      "s_branch 9f\n\t"
+      "15:\n\t"
+      "s_waitcnt vmcnt(12)\n\t"
+      "s_branch 9f\n\t"
+      "12:\n\t"
+      "s_bitcmp1_b32 %0, 3\n\t"
+      "s_cbranch_scc1 16f\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 17f\n\t"
+      "s_waitcnt vmcnt(16)\n\t"
+      "s_branch 9f\n\t"
+      "17:\n\t"
+      "s_waitcnt vmcnt(20)\n\t"
+      "s_branch 9f\n\t"
+      "16:\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 18f\n\t"
+      "s_waitcnt vmcnt(24)\n\t"
+      "s_branch 9f\n\t"
+      "18:\n\t"
+      "s_waitcnt vmcnt(28)\n\t"
+      "s_branch 9f\n\t"
+      "11:\n\t"
+      "s_bitcmp1_b32 %0, 4\n\t"
+      "s_cbranch_scc1 19f\n\t"
+      "s_bitcmp1_b32 %0, 3\n\t"
+      "s_cbranch_scc1 20f\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 21f\n\t"
+      "s_waitcnt vmcnt(32)\n\t"
+      "s_branch 9f\n\t"
+      "21:\n\t"
+      "s_waitcnt vmcnt(36)\n\t"
+      "s_branch 9f\n\t"
+      "20:\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 22f\n\t"
+      "s_waitcnt vmcnt(40)\n\t"
+      "s_branch 9f\n\t"
+      "22:\n\t"
+      "s_waitcnt vmcnt(44)\n\t"
+      "s_branch 9f\n\t"
+      "19:\n\t"
+      "s_bitcmp1_b32 %0, 3\n\t"
+      "s_cbranch_scc1 23f\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 24f\n\t"
+      "s_waitcnt vmcnt(48)\n\t"
+      "s_branch 9f\n\t"
+      "24:\n\t"
+      "s_waitcnt vmcnt(52)\n\t"
+      "s_branch 9f\n\t"
+      "23:\n\t"
+      "s_bitcmp1_b32 %0, 2\n\t"
+      "s_cbranch_scc1 25f\n\t"
+      "s_waitcnt vmcnt(56)\n\t"
+      "s_branch 9f\n\t"
+      "25:\n\t"
+      "s_waitcnt vmcnt(60)\n\t"
+      "s_branch 9f\n\t"
+      "9:"
+      :
+      : "s"(__builtin_amdgcn_readfirstlane(n))
+      : "memory", "scc");
+}
+
+template <bool ST>
 struct Loader {
   unsigned ring;             // LDS byte address of the ring
   Ctrl* c;
-  unsigned seq;              // items issued so far (this CU's item sequence over all phases)
-  unsigned pub;              // items published so far
-  unsigned outstanding;      // DMA instructions of the unpublished items
+  unsigned lid;              // which loader this is: it copies the items with seq % NLOAD == lid, and walks all of them
+  unsigned seq;              // items placed so far (this CU's item sequence over all phases)
+  unsigned pubseq;           // the oldest item of this loader that is not published yet
+  unsigned inflight;         // its unpublished items
+  unsigned outstanding;      // their DMA instructions
   unsigned long long nq;     // their instruction counts, one byte each, newest in the low byte
   unsigned head;             // ring offset behind the newest item
   unsigned tail_seq;         // oldest item the consumers have not released yet
@@ -156,22 +279,25 @@ struct Loader {
   bool wrapped;              // the newest item sits below the oldest one (free space: [head, tail_pos))
   int lane;
   bool skip;                 // experiment: issue nothing
+  bool nofree;               // experiment: never wait for ring space
+  unsigned long long* st;    // diagnostic: per-item shader-clock stamps of workgroup 0 (NULL otherwise)
 
   // publishes the oldest unpublished item once its bytes have landed (loads complete in order: wait for all but the
   // instructions issued after it)
   __device__ __forceinline__ void publish_one() {
-    const unsigned f = seq - pub;
-    const unsigned n_old = (unsigned)(nq >> (8u * (f - 1u))) & 0xffu;
+    const unsigned n_old = (unsigned)(nq >> (8u * (inflight - 1u))) & 0xffu;
     outstanding -= n_old;
     wait_vmcnt(outstanding);
-    lds_st(&c->full[pub % NCTRL], pub + 1u);
-    ++pub;
+    lds_st(&c->full[pubseq % NCTRL], pubseq + 1u);
+    if (ST && st && lane == 0 && pubseq < 128u) st[pubseq * 8u + 2u] = __builtin_readcyclecounter();
+    pubseq += NLOAD;
+    --inflight;
   }
   // releases the oldest item if every consumer has arrived for it
   __device__ __forceinline__ bool try_release() {
     const unsigned e = tail_seq % NCTRL;
     const unsigned d = __hip_atomic_load(&c->done[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const unsigned nxt = __hip_atomic_load(&c->start[(tail_seq + 1u) % NCTRL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned nxt = __hip_atomic_load(&c->start[lid][(tail_seq + 1u) % NCTRL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (__builtin_amdgcn_readfirstlane(d) != NCONS * (tail_seq / NCTRL + 1u)) return false;
     ++tail_seq;
     const unsigned np = tail_seq < seq ? __builtin_amdgcn_readfirstlane(nxt) : head;
@@ -180,30 +306,38 @@ struct Loader {
     return true;
   }
   __device__ __forceinline__ bool fits(unsigned pos, unsigned sz) const {
+    if (nofree) return true;
     if (tail_seq == seq) return true;                       // empty ring
     if (seq - tail_seq >= (unsigned)MAX_IN_RING) return false;
     if (pos == head) return wrapped ? pos + sz <= tail_pos : true;  // (ring_place saw to pos + sz <= RING_BYTES)
     return !wrapped && sz <= tail_pos;                      // wrapping to offset 0: below the oldest item
   }
 
-  // the items [a, b) of one segment (pair: of ffn_gate and ffn_up together); plane geometry hoisted out of the item loop
-  __device__ __forceinline__ bool run_seg(const SegDesc s, const SegDesc s2, bool pair, int cols, int rpi, int a, int b) {
-    int rb[4], nins = 0;
+  // the items [a, b) of one segment (PAIR: of ffn_gate and ffn_up together). The format is a compile-time parameter:
+  // an item is NP (x 2) straight copies whose sizes are fixed per segment
+  template <int TYPE, bool PAIR>
+  __device__ __forceinline__ bool run_seg(const SegDesc s, const SegDesc s2, int cols, int rpi, int a, int b) {
+    constexpr int NP = TYPE == TL_Q6_K ? 4 : 2;
+    int rb[NP], ni[NP], nins = 0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      rb[p] = plane_row_bytes(s.type, p, cols);
-      nins += (rpi * rb[p] + 1023) >> 10;
+    for (int p = 0; p < NP; ++p) {
+      rb[p] = plane_row_bytes(TYPE, p, cols);
+      ni[p] = (rpi * rb[p] + 1023) >> 10;
+      nins += ni[p];
     }
-    const unsigned half = (unsigned)(nins << 10), sz = pair ? 2u * half : half;
-    if (pair) nins *= 2;
+    const unsigned half = (unsigned)(nins << 10), sz = PAIR ? 2u * half : half;
+    if (PAIR) nins *= 2;
+    const unsigned lane16 = (unsigned)lane * 16u;
     for (int li = a; li < b; ++li) {
+      const bool mine = seq % NLOAD == lid;  // (the other loaders' items are placed too: every loader keeps the whole picture)
       // the queue stays inside what vmcnt and the count register can hold
-      while (pub < seq && (outstanding + (unsigned)nins > MAX_OUTSTANDING || seq - pub >= (unsigned)MAX_UNPUBLISHED)) publish_one();
+      while (mine && inflight > 0u && (outstanding + (unsigned)nins > MAX_OUTSTANDING || inflight >= (unsigned)MAX_UNPUBLISHED)) publish_one();
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 0u] = __builtin_readcyclecounter();
       const unsigned pos = ring_place(head, sz);
       if (!fits(pos, sz)) {
         while (try_release() && !fits(pos, sz)) {}
         if (!fits(pos, sz)) {
-          while (pub < seq) publish_one();  // nothing can be issued anyway: hand over everything that is in flight
+          while (inflight > 0u) publish_one();  // nothing can be issued anyway: hand over everything that is in flight
           for (unsigned spins = 0; !fits(pos, sz); ++spins) {
             if (try_release()) continue;
             if ((spins & 63u) == 63u && (lds_ld(&c->fail) != 0u || spins > SPIN_LIMIT)) {
@@ -220,31 +354,39 @@ struct Loader {
       } else if (pos != head) {
         wrapped = true;
       }
-      lds_st(&c->start[seq % NCTRL], pos);
+      lds_st(&c->start[lid][seq % NCTRL], pos);
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 1u] = __builtin_readcyclecounter();
       unsigned dst = ring + pos;
       const int row0 = li * rpi;
       const int rows_valid = s.rows - row0 < rpi ? s.rows - row0 : rpi;
 #pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        if (hf == 1 && !pair) break;
+      for (int hf = 0; hf < (PAIR ? 2 : 1); ++hf) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          if (rb[p] == 0) break;
-          const int bytes = rpi * rb[p], valid = rows_valid * rb[p];
+        for (int p = 0; p < NP; ++p) {
           const uint8_t* base = (hf ? s2.p[p] : s.p[p]) + (size_t)row0 * rb[p];
-          for (int o = 0; o < bytes && !skip; o += 1024) {
-            // lanes past the item's valid rows re-read its first 16 bytes (a lane that straddles the end of the last plane
-            // of a matrix reads < 16 bytes beyond it: tl_qweight_upload allocates that much slack)
-            int lo = o + lane * 16;
-            if (lo >= valid) lo = 0;
-            dma_1k(base + lo, dst + (unsigned)o);
+          if (skip || !mine) {
+          } else if (rows_valid == rpi) {
+            // whole item: straight copies; the lanes of a last, partial KiB read on into the next rows (or, behind the
+            // last row of the last plane, into the slack tl_qweight_upload allocates)
+            dma_run(base, lane16, dst, ni[p]);
+          } else {
+            const int bytes = rpi * rb[p], valid = rows_valid * rb[p];
+            for (int o = 0; o < bytes; o += 1024) {  // last item of a matrix: lanes past its rows re-read its first bytes
+              int lo = o + lane * 16;
+              if (lo >= valid) lo = 0;
+              dma_1k(base + lo, dst + (unsigned)o);
+            }
           }
-          dst += (unsigned)round1k(bytes);
+          dst += (unsigned)(ni[p] << 10);
         }
       }
       head = pos + sz;
-      nq = (nq << 8) | (unsigned)nins;
-      outstanding += (unsigned)nins;
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 3u] = __builtin_readcyclecounter();
+      if (mine) {
+        nq = (nq << 8) | (unsigned)nins;
+        outstanding += (unsigned)nins;
+        ++inflight;
+      }
       ++seq;
     }
     return true;
@@ -255,16 +397,34 @@ struct Loader {
     const bool pair = ph.pair != 0;
     const int first = (int)((long)n_items * cu / ncu), last = (int)((long)n_items * (cu + 1) / ncu);
     int sb = 0;  // first item of the segment
-    for (int sg = 0; sg < nseg; ++sg) {
+    bool ok = true;
+    for (int sg = 0; sg < nseg && ok; ++sg) {
       const int cnt = ph.items[sg];
       const int a = first > sb ? first - sb : 0, b = last - sb < cnt ? last - sb : cnt;
-      if (a < b && !run_seg(ph.seg[sg], ph.seg[1], pair, cols, ph.rpi[sg], a, b)) return false;
+      if (a < b) {
+        const int rpi = ph.rpi[sg];
+        if (pair) {
+          switch (ph.seg[sg].type) {
+            case TL_Q4_K: ok = run_seg<TL_Q4_K, true>(ph.seg[0], ph.seg[1], cols, rpi, a, b); break;
+            case TL_Q6_K: ok = run_seg<TL_Q6_K, true>(ph.seg[0], ph.seg[1], cols, rpi, a, b); break;
+            case TL_Q8_0: ok = run_seg<TL_Q8_0, true>(ph.seg[0], ph.seg[1], cols, rpi, a, b); break;
+            default: ok = run_seg<TL_Q8_K, true>(ph.seg[0], ph.seg[1], cols, rpi, a, b); break;
+          }
+        } else {
+          switch (ph.seg[sg].type) {
+            case TL_Q4_K: ok = run_seg<TL_Q4_K, false>(ph.seg[sg], ph.seg[sg], cols, rpi, a, b); break;
+            case TL_Q6_K: ok = run_seg<TL_Q6_K, false>(ph.seg[sg], ph.seg[sg], cols, rpi, a, b); break;
+            case TL_Q8_0: ok = run_seg<TL_Q8_0, false>(ph.seg[sg], ph.seg[sg], cols, rpi, a, b); break;
+            default: ok = run_seg<TL_Q8_K, false>(ph.seg[sg], ph.seg[sg], cols, rpi, a, b); break;
+          }
+        }
+      }
       sb += cnt;
     }
-    return true;
+    return ok;
   }
   __device__ __forceinline__ void drain() {
-    while (pub < seq) publish_one();
+    while (inflight > 0u) publish_one();
   }
 };
 
@@ -298,6 +458,7 @@ struct XSpan {  // a consumer's span of the input vector: this lane's chunk and 
   bool act;  // the lane's chunk exists (cols is not always a multiple of 2048)
 };
 
+template <bool ST>
 struct Consumer {
   const uint8_t* ring;
   Ctrl* c;
@@ -305,6 +466,8 @@ struct Consumer {
   unsigned head;   // ring offset behind the newest item consumed (the loader's recurrence)
   int wave, lane;  // wave: 0..NCONS-1
   bool skip;       // experiment: no arithmetic
+  bool nofull;     // experiment: never wait for an item to land
+  unsigned long long* st;  // diagnostic stamps (wave 0 of workgroup 0)
   // the epilogue this wave still owes (item seq % NCONS == wave): run one item later, when the other waves' partials
   // are almost surely in and the wait costs a single LDS read
   struct Pending {
@@ -363,19 +526,19 @@ struct Consumer {
       const uint8_t* item = ring + pos;
       // the FULL word and the units' bytes are read in one go: LDS serves a wave's reads in order, so bytes read behind
       // a FULL word that matches are the item's
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 4u] = __builtin_readcyclecounter();
       Chunk<TYPE> k0, k1;
-      for (unsigned spins = 0;; ++spins) {
-        const unsigned f = __hip_atomic_load(&c->full[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      unsigned f = __hip_atomic_load(&c->full[entry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      if (act0) chunk_from_lds<TYPE>(k0, item + off0, cols, rpi, r0, (unsigned)chunk);
+      if (act1) chunk_from_lds<TYPE>(k1, item + off1, cols, rpi, r1, (unsigned)chunk);
+      if (!nofull && __builtin_amdgcn_readfirstlane(f) != seq + 1u) {  // not there yet: wait on the word alone, then read again
+        if (!lds_wait_eq(&c->full[entry], seq + 1u, c)) return false;
         asm volatile("" ::: "memory");
         if (act0) chunk_from_lds<TYPE>(k0, item + off0, cols, rpi, r0, (unsigned)chunk);
         if (act1) chunk_from_lds<TYPE>(k1, item + off1, cols, rpi, r1, (unsigned)chunk);
-        if (__builtin_amdgcn_readfirstlane(f) == seq + 1u) break;
-        if ((spins & 63u) == 63u && (lds_ld(&c->fail) != 0u || spins > SPIN_LIMIT)) {
-          lds_st(&c->fail, 1u);
-          return false;
-        }
-        __builtin_amdgcn_s_sleep(1);
       }
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 5u] = __builtin_readcyclecounter();
       if (act0) {
         const float d = k0.dot(xs.x, xs.s0, xs.s1, chunk & 7);
         const float y = wave_sum_lane63(xs.act ? d : 0.0f);
@@ -388,9 +551,11 @@ struct Consumer {
       }
       asm volatile("" ::: "memory");
       if (lane == 0) lds_add(&c->done[entry], 1u);  // (after the partials in program order: LDS keeps a wave's order)
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 6u] = __builtin_readcyclecounter();
       if (!flush_epilogue()) return false;          // the item before this one, if its epilogue was this wave's
       if ((int)(seq % NCONS) == wave)
         pe = Pending{true, entry, NCONS * (seq / NCTRL + 1u), out, resid, li * rpi, rows, rpi, nspans, pair};
+      if (ST && st && lane == 0 && seq < 128u) st[seq * 8u + 7u] = __builtin_readcyclecounter();
       ++seq;
     }
     return true;
@@ -449,8 +614,10 @@ __device__ __forceinline__ void load_span(XSpan& xs, const float* x, const float
 // One launch = phases [first, first + count) of `descs`, back to back. (Stage 1: no cross-CU hand-off between phases —
 // every phase reads an x that was complete before the launch.)
 // dbg (experiments): bit 0 consumers skip the arithmetic, bit 1 the loader publishes items without copying them
+template <bool ST>
 __global__ __launch_bounds__(NTHREADS) void stream_kernel(const PhaseDesc* __restrict__ descs, int first, int count,
-                                                         unsigned* __restrict__ err, int dbg) {
+                                                         unsigned* __restrict__ err, int dbg,
+                                                         unsigned long long* __restrict__ stamps) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t lds[];
   Ctrl* c = reinterpret_cast<Ctrl*>(lds + RING_BYTES);
   const int lane = threadIdx.x & 63;
@@ -459,20 +626,30 @@ __global__ __launch_bounds__(NTHREADS) void stream_kernel(const PhaseDesc* __res
   __syncthreads();  // the only workgroup barrier: from here on the loader runs on its own
   const int cu = blockIdx.x, ncu = gridDim.x;
   bool ok = true;
-  if (wave == NCONS) {
-    Loader L = {(unsigned)(unsigned long long)lds, c, 0u, 0u, 0u, 0ull, 0u, 0u, 0u, false, lane, (dbg & 2) != 0};
+  if (wave >= NCONS) {
+    // the loaders go ahead of the consumers in issue arbitration: they are the youngest waves of the workgroup and would
+    // otherwise get the slots the consumers leave (measured: 23 -> 20 us for a 66 MB phase)
+    if (!(dbg & 4)) __builtin_amdgcn_s_setprio(3);
+    const unsigned lid = (unsigned)(wave - NCONS);
+    Loader<ST> L = {(unsigned)(unsigned long long)lds, c, lid, 0u, lid, 0u, 0u, 0ull, 0u, 0u, 0u, false, lane, (dbg & 2) != 0,
+                    (dbg & 32) != 0, (blockIdx.x == 0 && stamps && lid == 0u) ? &c->stamps[0][0] : nullptr};
     for (int p = first; p < first + count && ok; ++p) ok = L.run_phase(descs[p], cu, ncu);
     L.drain();
   } else {
-    Consumer C = {lds, c, 0u, 0u, wave, lane, (dbg & 1) != 0, {}};
+    const int cw = wave;
+    Consumer<ST> C = {lds, c, 0u, 0u, cw, lane, (dbg & 1) != 0, (dbg & 16) != 0, (blockIdx.x == 0 && cw == 0 && stamps) ? &c->stamps[0][0] : nullptr, {}};
     for (int p = first; p < first + count && ok; ++p) {
       const PhaseDesc& ph = descs[p];
       XSpan xs;
-      load_span(xs, ph.x, nullptr, 1.0f, ph.cols, wave % ph.nspans, lane);
+      load_span(xs, ph.x, nullptr, 1.0f, ph.cols, cw % ph.nspans, lane);
       ok = C.run_phase(ph, xs, cu, ncu);
     }
   }
   if (!ok && lane == 0) atomicExch(err, 1u);
+  if (ST && stamps && blockIdx.x == 0) {  // diagnostic run: every wave of the workgroup is through, then the stamps go out
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < 128u * 8u; i += NTHREADS) stamps[i] = (&c->stamps[0][0])[i];
+  }
 }
 
 int g_attr_done[64] = {};
@@ -514,7 +691,9 @@ extern "C" int tl_stream_matvec(const tl_qweight* const* ws, int nw, const float
   const size_t lds = (size_t)RING_BYTES + sizeof(Ctrl);
   TL_REQUIRE(lds <= 160 * 1024, "tl_stream_matvec: %zu bytes of LDS", lds);
   if (dev < 64 && !g_attr_done[dev]) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               160 * 1024));
+    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                160 * 1024));
     g_attr_done[dev] = 1;
   }
@@ -545,11 +724,19 @@ extern "C" int tl_stream_matvec(const tl_qweight* const* ws, int nw, const float
   TL_HIP(hipEventCreate(&e0));
   TL_HIP(hipEventCreate(&e1));
   const int dbg = getenv("TL_STREAM_DBG") ? atoi(getenv("TL_STREAM_DBG")) : 0;
-  stream_kernel<<<ncu, NTHREADS, lds, s>>>(ddev, 0, nw, err, dbg);  // warm-up
+  unsigned long long* stamps = nullptr;
+  const char* stamp_path = getenv("TL_STREAM_STAMPS");
+  if (stamp_path) {
+    TL_HIP(hipMalloc(&stamps, 128 * 8 * 8));
+    TL_HIP(hipMemset(stamps, 0, 128 * 8 * 8));
+  }
+  stream_kernel<false><<<ncu, NTHREADS, lds, s>>>(ddev, 0, nw, err, dbg, nullptr);  // warm-up
   TL_HIP(hipEventRecord(e0, s));
-  for (int r = 0; r < reps; ++r) stream_kernel<<<ncu, NTHREADS, lds, s>>>(ddev, 0, nw, err, dbg);
+  for (int r = 0; r < reps; ++r) stream_kernel<false><<<ncu, NTHREADS, lds, s>>>(ddev, 0, nw, err, dbg, nullptr);
   TL_HIP(hipEventRecord(e1, s));
+  if (stamps) stream_kernel<true><<<ncu, NTHREADS, lds, s>>>(ddev, 0, nw, err, dbg, stamps);  // (the stamped build, untimed)
   TL_HIP(hipEventSynchronize(e1));
+  TL_HIP(hipStreamSynchronize(s));
   TL_HIP(hipGetLastError());
   float ms = 0.f;
   TL_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -558,6 +745,19 @@ extern "C" int tl_stream_matvec(const tl_qweight* const* ws, int nw, const float
   TL_HIP(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
   hipEventDestroy(e0);
   hipEventDestroy(e1);
+  if (stamps) {
+    unsigned long long* hs = new unsigned long long[128 * 8];
+    hipMemcpy(hs, stamps, 128 * 8 * 8, hipMemcpyDeviceToHost);
+    if (FILE* f = fopen(stamp_path, "w")) {
+      for (int i = 0; i < 128 && hs[i * 8] != 0; ++i) {
+        for (int k = 0; k < 8; ++k) fprintf(f, "%llu ", hs[i * 8 + k] ? hs[i * 8 + k] - hs[0] : 0ull);
+        fprintf(f, "\n");
+      }
+      fclose(f);
+    }
+    delete[] hs;
+    hipFree(stamps);
+  }
   hipFree(ddev);
   hipFree(err);
   TL_REQUIRE(herr == 0, "tl_stream_matvec: a wave of the engine gave up waiting (ring protocol error)");

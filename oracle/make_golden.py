@@ -26,9 +26,85 @@ OUT = os.path.join(ROOT, "tests", "golden")
 NAMES = {Q4_K: "q4_k", Q6_K: "q6_k", Q8_0: "q8_0", Q8_K: "q8_k"}
 
 
+def extended_gguf_bytes(cfg, tensors, alignment, extra_tensor=None):
+    """A synthetic GGUF v3 file with every scalar metadata type, the tokenizer arrays the reference retains
+    (gguf_parser.cpp:245-348) and a non-default alignment: bytes of the file."""
+    import struct
+    gs = S._gs
+    V = cfg["vocab"]
+    toks = [f"<tok{i}>" for i in range(V)]
+    kvs = [
+        S._kv_str("general.architecture", "llama"), S._kv_str("general.name", "golden g4"),
+        S._kv_u32("general.alignment", alignment),
+        S._kv_u32("llama.embedding_length", cfg["hidden"]), S._kv_u32("llama.feed_forward_length", cfg["inter"]),
+        S._kv_u32("llama.attention.head_count", cfg["n_heads"]),
+        gs("llama.attention.head_count_kv") + struct.pack("<IQ", 10, cfg["n_kv_heads"]),      # u64
+        gs("llama.block_count") + struct.pack("<Ii", 5, cfg["n_layers"]),                       # i32
+        gs("llama.context_length") + struct.pack("<IH", 2, cfg["max_pos"]),                     # u16
+        S._kv_u32("llama.vocab_size", V),
+        S._kv_f32("llama.attention.layer_norm_rms_epsilon", cfg["eps"]),
+        gs("llama.rope.freq_base") + struct.pack("<Id", 12, cfg["rope_theta"]),                 # f64
+        gs("tokenizer.ggml.bos_token_id") + struct.pack("<IB", 0, 1),                           # u8
+        gs("tokenizer.ggml.eos_token_id") + struct.pack("<Ib", 1, 2),                           # i8
+        gs("tokenizer.ggml.unknown_token_id") + struct.pack("<Ih", 3, -1),                      # i16
+        gs("golden.some_i64") + struct.pack("<Iq", 11, -(1 << 40)),                             # i64
+        gs("golden.some_bool") + struct.pack("<IB", 7, 1),                                      # bool
+        S._kv_str("tokenizer.ggml.model", "llama"),
+        gs("tokenizer.ggml.tokens") + struct.pack("<IIQ", 9, 8, V) + b"".join(gs(t) for t in toks),
+        gs("tokenizer.ggml.scores") + struct.pack("<IIQ", 9, 6, V) + struct.pack(f"<{V}f", *[-float(i) for i in range(V)]),
+        gs("tokenizer.ggml.token_type") + struct.pack("<IIQ", 9, 5, V) + struct.pack(f"<{V}i", *([1] * V)),
+        gs("golden.skipped_array") + struct.pack("<IIQ", 9, 4, 3) + struct.pack("<3I", 7, 8, 9),  # u32 array: skipped
+    ]
+    items = list(tensors.items()) + ([extra_tensor] if extra_tensor else [])
+    infos, offset, order = [], 0, []
+    for name, (typ, arr, rows, cols) in items:
+        dims = [cols] if typ == S.F32 and rows == 1 else [cols, rows]
+        infos.append(gs(name) + struct.pack("<I", len(dims)) + b"".join(struct.pack("<Q", d) for d in dims) +
+                     struct.pack("<IQ", typ, offset))
+        order.append((np.ascontiguousarray(arr).tobytes(), offset))
+        offset = (offset + len(order[-1][0]) + alignment - 1) // alignment * alignment
+    head = struct.pack("<IIQQ", 0x46554747, 3, len(infos), len(kvs)) + b"".join(kvs) + b"".join(infos)
+    head += b"\0" * ((-len(head)) % alignment)
+    body = bytearray(offset)
+    for raw, off in order:
+        body[off:off + len(raw)] = raw
+    return head + bytes(body)
+
+
+def make_g4(ref):
+    """G4: a synthetic GGUF file and what the reference's OWN parser (load_gguf_meta, gguf_parser.cpp:123; size rules
+    quantization.cpp:646-717) makes of it — tensor names, types, dims, offsets, element and byte counts, a CRC of the bytes
+    where the reference's consumers read them, alignment, metadata; plus the parser's verdict on a file that holds a
+    Q8_K tensor (it throws: ggml_type_block_size returns 0 for Q8_K)."""
+    import json
+    import tempfile
+    cfg = dict(hidden=256, inter=256, n_heads=4, n_kv_heads=2, n_layers=1, vocab=32, max_pos=4096, eps=1e-5, rope_theta=500000.0)
+    cfg, tensors = S.build_model(cfg, "q4_k_m", seed=11)
+    raw = extended_gguf_bytes(cfg, tensors, 64)
+    rng = np.random.default_rng(4)
+    q8k = ("blk.0.extra_q8k.weight", (Q8_K, S.random_blocks(Q8_K, 2, rng), 2, 256))
+    raw_q8k = extended_gguf_bytes(cfg, dict(list(tensors.items())[:1]), 32, extra_tensor=q8k)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, blob in (("good", raw), ("q8k", raw_q8k)):
+            path = os.path.join(d, tag + ".gguf")
+            with open(path, "wb") as f:
+                f.write(blob)
+            parsed = ref.gguf_parse(path, use_mmap=True)
+            assert parsed == ref.gguf_parse(path, use_mmap=False), "mmap and bulk-read parses differ"
+            out[tag] = np.frombuffer(blob, np.uint8)
+            out[tag + "_ref_parse_json"] = np.frombuffer(json.dumps(parsed, sort_keys=True).encode(), np.uint8)
+    assert "error" not in json.loads(bytes(out["good_ref_parse_json"]))
+    assert "error" in json.loads(bytes(out["q8k_ref_parse_json"]))
+    np.savez_compressed(os.path.join(OUT, "g4_gguf.npz"), **out)
+    print("g4_gguf.npz", os.path.getsize(os.path.join(OUT, "g4_gguf.npz")), json.loads(bytes(out["q8k_ref_parse_json"])))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref, orc = Ref(), Oracle()
+    if sys.argv[1:] == ["g4"]:  # only the GGUF fixture (the others are unchanged since round 1)
+        return make_g4(ref)
     rng = np.random.default_rng(20261110)
 
     # G0: fp16 -> fp32 for ALL 65536 halves, both flag values (bits), + fp32->fp16 samples
@@ -109,6 +185,7 @@ def main():
             g3[f"{tag}_p{plen}_prompt"] = prompt
         m.close()
     np.savez_compressed(os.path.join(OUT, "g3_e2e.npz"), **g3)
+    make_g4(ref)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

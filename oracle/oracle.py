@@ -309,6 +309,61 @@ class Ref:
         L.ref_rope_batch.argtypes = [_fp, _fp] + [C.c_int] * 5 + [_fp, C.c_int, C.c_int]
         L.ref_softmax.argtypes = [_fp, _fp, C.c_int]
         L.ref_silu.argtypes = [_fp, _fp, C.c_int]
+        if hasattr(L, "ref_gguf_open"):  # (a libtlref.so built before round 2 lacks the parser / timing doorways)
+            L.ref_last_error.restype = C.c_char_p
+            L.ref_gguf_open.restype = C.c_long
+            L.ref_gguf_open.argtypes = [C.c_char_p, C.c_int]
+            L.ref_gguf_alignment.restype = C.c_ulonglong
+            L.ref_gguf_meta_count.restype = C.c_long
+            L.ref_gguf_tensor.argtypes = [C.c_long, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint), C.POINTER(C.c_uint),
+                                          C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong),
+                                          C.POINTER(C.c_ulonglong)]
+            L.ref_gguf_tensor_bytes.restype = C.c_long
+            L.ref_gguf_tensor_bytes.argtypes = [C.c_long, C.c_void_p, C.c_size_t]
+            L.ref_gguf_meta.argtypes = [C.c_long, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong),
+                                        C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
+            L.ref_time_q4k_dequant_matvec.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
+                                                      C.POINTER(C.c_double)]
+
+    def gguf_parse(self, path, use_mmap=True):
+        """The file as the reference's load_gguf_meta (gguf_parser.cpp:123) sees it: {"alignment", "tensors": [dict],
+        "metadata": {key: value}} or {"error": text} when the parser throws."""
+        import zlib
+        L = self.L
+        n = L.ref_gguf_open(os.fsencode(path), int(use_mmap))
+        if n < 0:
+            return {"error": L.ref_last_error().decode(errors="replace")}
+        out = {"alignment": int(L.ref_gguf_alignment()), "tensors": [], "metadata": {}}
+        name = C.create_string_buffer(512)
+        for i in range(n):
+            typ, nd = C.c_uint(), C.c_uint()
+            dims = (C.c_ulonglong * 4)()
+            off, ne, nb = C.c_ulonglong(), C.c_ulonglong(), C.c_ulonglong()
+            assert L.ref_gguf_tensor(i, name, 512, C.byref(typ), C.byref(nd), dims, C.byref(off), C.byref(ne), C.byref(nb)) == 0
+            raw = np.empty(nb.value, np.uint8)
+            got = L.ref_gguf_tensor_bytes(i, _v(raw), raw.size)
+            out["tensors"].append({"name": name.value.decode(), "type": typ.value, "dims": list(dims)[: nd.value],
+                                   "offset": off.value, "num_elements": ne.value, "size_in_bytes": nb.value,
+                                   "crc32": zlib.crc32(raw.tobytes()) if got == nb.value else None})
+        key, sval = C.create_string_buffer(512), C.create_string_buffer(4096)
+        for i in range(L.ref_gguf_meta_count()):
+            kind, u, sg, f = C.c_int(), C.c_ulonglong(), C.c_longlong(), C.c_double()
+            assert L.ref_gguf_meta(i, key, 512, C.byref(kind), C.byref(u), C.byref(sg), C.byref(f), sval, 4096) == 0
+            v = {0: u.value, 1: sg.value, 2: f.value, 3: bool(u.value), 4: sval.value.decode(errors="replace"),
+                 5: ["array", u.value]}[kind.value]
+            out["metadata"][key.value.decode()] = v
+        L.ref_gguf_close()
+        return out
+
+    def time_q4k_dequant_matvec(self, blocks, x, rows, cols, reps=3):
+        """(dequantize seconds, mat-vec seconds, y): the reference's dequantize_vector_q4k_to_f32 +
+        matvec_f32_f32_vector_cpu on one tensor, best of `reps`, timed inside the library (no marshalling copies)."""
+        blocks = np.ascontiguousarray(blocks)
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty(rows, np.float32)
+        d, m = C.c_double(), C.c_double()
+        assert self.L.ref_time_q4k_dequant_matvec(_v(blocks), _f(x), _f(y), rows, cols, reps, C.byref(d), C.byref(m)) == 0
+        return d.value, m.value, y
 
     def fp16_to_fp32_bits(self, h, is_scale=False):
         return int(np.float32(self.L.ref_fp16_to_fp32(int(h), int(is_scale))).view(np.uint32))

@@ -6,11 +6,18 @@
 // oracle/_ref/libtlref.so. The result is used (a) to validate the C restatement in tl_oracle.c and
 // (b) by oracle/make_golden.py to produce the committed fixtures under tests/golden/.
 // Each wrapper only marshals plain buffers into the std::vector signatures the reference uses.
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
+#include <memory>
+#include <string>
+#include <type_traits>
 #include <utility>
+#include <variant>
 #include <vector>
 
+#include "gguf_parser.h"
 #include "logger.h"
 #include "quantization.h"
 #include "utils.h"
@@ -169,6 +176,132 @@ void ref_silu(const float* x, float* out, int n) {
   std::vector<float> xv(x, x + n), o(n);
   silu_cpu(xv, o);
   std::memcpy(out, o.data(), (size_t)n * sizeof(float));
+}
+
+// ---- the reference's own GGUF parser (load_gguf_meta, gguf_parser.cpp:123) over a file on disk ------------------------
+// One file at a time. ref_gguf_open returns the tensor count, or -1 with the parser's exception text in ref_last_error().
+static std::unique_ptr<GGUFData> g_gguf;
+static std::vector<std::pair<std::string, GGUFMetadataValue>> g_meta;
+static std::string g_err;
+
+const char* ref_last_error() { return g_err.c_str(); }
+
+long ref_gguf_open(const char* path, int use_mmap) {
+  g_gguf.reset();
+  g_meta.clear();
+  g_err.clear();
+  try {
+    g_gguf = std::make_unique<GGUFData>(load_gguf_meta(path, use_mmap != 0));
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+  for (const auto& kv : g_gguf->metadata) g_meta.emplace_back(kv.first, kv.second);
+  return static_cast<long>(g_gguf->tensor_infos.size());
+}
+void ref_gguf_close() {
+  g_gguf.reset();
+  g_meta.clear();
+}
+unsigned long long ref_gguf_alignment() { return g_gguf ? g_gguf->data_alignment : 0; }
+long ref_gguf_meta_count() { return g_gguf ? static_cast<long>(g_meta.size()) : -1; }
+
+// tensor i as the reference recorded it; returns 0, or -1 for a bad index
+int ref_gguf_tensor(long i, char* name, size_t name_len, unsigned* type, unsigned* n_dims, unsigned long long dims[4],
+                    unsigned long long* offset, unsigned long long* num_elements, unsigned long long* size_in_bytes) {
+  if (!g_gguf || i < 0 || (size_t)i >= g_gguf->tensor_infos.size()) return -1;
+  const GGUFTensorInfo& t = g_gguf->tensor_infos[(size_t)i];
+  std::snprintf(name, name_len, "%s", t.name.c_str());
+  *type = static_cast<unsigned>(t.type);
+  *n_dims = static_cast<unsigned>(t.shape.size());
+  for (size_t d = 0; d < 4; ++d) dims[d] = d < t.shape.size() ? t.shape[d] : 0;
+  *offset = t.offset;
+  *num_elements = t.num_elements;
+  *size_in_bytes = t.size_in_bytes;
+  return 0;
+}
+
+// the bytes of tensor i where the reference's consumers read them (weight_management.cpp:856-875: mapped block +
+// offset_diff_for_mmap + offset, or the bulk-read vector + offset); returns the byte count copied (<= cap), -1 on error
+long ref_gguf_tensor_bytes(long i, void* out, size_t cap) {
+  if (!g_gguf || i < 0 || (size_t)i >= g_gguf->tensor_infos.size()) return -1;
+  const GGUFTensorInfo& t = g_gguf->tensor_infos[(size_t)i];
+  const uint8_t* base = nullptr;
+  size_t avail = 0;
+  if (g_gguf->mapped_tensor_data && g_gguf->mapped_tensor_data != GGUFData::MMapFailure) {
+    base = static_cast<const uint8_t*>(g_gguf->mapped_tensor_data) + g_gguf->offset_diff_for_mmap;
+    avail = g_gguf->mapped_tensor_data_size - g_gguf->offset_diff_for_mmap;
+  } else {
+    base = g_gguf->tensor_data.data();
+    avail = g_gguf->tensor_data.size();
+  }
+  if (!base || t.offset + t.size_in_bytes > avail) return -1;
+  const size_t n = t.size_in_bytes < cap ? t.size_in_bytes : cap;
+  std::memcpy(out, base + t.offset, n);
+  return static_cast<long>(n);
+}
+
+// metadata entry i (map order): kind 0 unsigned, 1 signed, 2 float, 3 bool, 4 string, 5 array (u = length)
+int ref_gguf_meta(long i, char* key, size_t key_len, int* kind, unsigned long long* u, long long* s, double* f, char* str,
+                  size_t str_len) {
+  if (!g_gguf || i < 0 || (size_t)i >= g_meta.size()) return -1;
+  std::snprintf(key, key_len, "%s", g_meta[(size_t)i].first.c_str());
+  *u = 0;
+  *s = 0;
+  *f = 0.0;
+  if (str_len) str[0] = 0;
+  std::visit(
+      [&](const auto& v) {
+        using T = std::decay_t<decltype(v)>;
+        if constexpr (std::is_same_v<T, bool>) {
+          *kind = 3;
+          *u = v ? 1 : 0;
+        } else if constexpr (std::is_same_v<T, std::string>) {
+          *kind = 4;
+          std::snprintf(str, str_len, "%s", v.c_str());
+        } else if constexpr (std::is_same_v<T, GGUFArray>) {
+          *kind = 5;
+          *u = v.len;
+        } else if constexpr (std::is_floating_point_v<T>) {
+          *kind = 2;
+          *f = static_cast<double>(v);
+        } else if constexpr (std::is_signed_v<T>) {
+          *kind = 1;
+          *s = static_cast<long long>(v);
+        } else {
+          *kind = 0;
+          *u = static_cast<unsigned long long>(v);
+        }
+      },
+      g_meta[(size_t)i].second);
+  return 0;
+}
+
+// ---- timing of the reference's own decode-path pair on one tensor, with no marshalling inside the timed region ------
+// dequantize_vector_q4k_to_f32 (quantization.cpp:1054; what ensure_*_dequantized runs once per token and tensor,
+// weight_management.cpp:44-196) followed by matvec_f32_f32_vector_cpu (utils.cpp:349): seconds of each, best of `reps`.
+int ref_time_q4k_dequant_matvec(const void* blocks, const float* x, float* y, int rows, int cols, int reps, double* dequant_s,
+                                double* matvec_s) {
+  const size_t nblocks = (size_t)rows * cols / GGML_QK_K;
+  const std::vector<block_q4_K> b = as_blocks<block_q4_K>(blocks, nblocks);
+  const std::vector<float> xv(x, x + cols);
+  std::vector<float> out;
+  double best_d = 1e30, best_m = 1e30;
+  for (int r = 0; r < reps; ++r) {
+    std::vector<float> w;  // a fresh vector per repetition, as after clear_layer_dequantized_weights
+    const auto t0 = std::chrono::steady_clock::now();
+    dequantize_vector_q4k_to_f32(b, w, nblocks * GGML_QK_K, 0);
+    const auto t1 = std::chrono::steady_clock::now();
+    matvec_f32_f32_vector_cpu(w, xv, out, rows, cols);
+    const auto t2 = std::chrono::steady_clock::now();
+    const double d = std::chrono::duration<double>(t1 - t0).count(), m = std::chrono::duration<double>(t2 - t1).count();
+    if (d < best_d) best_d = d;
+    if (m < best_m) best_m = m;
+  }
+  std::memcpy(y, out.data(), out.size() * sizeof(float));
+  *dequant_s = best_d;
+  *matvec_s = best_m;
+  return 0;
 }
 
 }  // extern "C"

@@ -79,6 +79,67 @@ def test_gguf_reader_rejects_malformed_files(H, pkg, tmp_path):
     g.close()
 
 
+def test_gguf_reader_matches_the_reference_parser(H, golden, tmp_path):
+    """tests/golden/g4_gguf.npz holds a synthetic GGUF file (every scalar metadata type, tokenizer arrays, alignment 64)
+    and what the REFERENCE'S OWN load_gguf_meta (gguf_parser.cpp:123) parsed from it (oracle/make_golden.py g4):
+    tlhost::GGUFFile must report the same tensors, byte for byte, and the same metadata."""
+    import json
+    import zlib
+    g4 = golden["g4_gguf"]
+    want = json.loads(bytes(g4["good_ref_parse_json"]))
+    path = str(tmp_path / "g4.gguf")
+    g4["good"].tofile(path)
+    g = H.GGUF(path)
+    nt, nm, al = g.counts()
+    assert nt == len(want["tensors"]) and al == want["alignment"] == 64 and nm == len(want["metadata"])
+    for i, t in enumerate(want["tensors"]):
+        name, typ, dims, off, raw = g.tensor(i)
+        assert (name, typ, dims, off) == (t["name"], t["type"], t["dims"], t["offset"])
+        assert raw.size == t["size_in_bytes"] and zlib.crc32(raw.tobytes()) == t["crc32"], name
+        assert int(np.prod(dims)) == t["num_elements"]
+    for key, v in want["metadata"].items():
+        if isinstance(v, bool) or isinstance(v, list):
+            continue  # (bools and arrays are not exposed one by one through the C view; their count is checked above)
+        if isinstance(v, str):
+            assert g.meta_string(key) == v, key
+        elif isinstance(v, int):
+            assert g.meta_int(key) == v, key
+        else:
+            assert g.meta_float(key) == pytest.approx(v, rel=0, abs=0), key
+    mc = g.model_config()
+    assert (mc["n_kv_heads"], mc["n_layers"], mc["max_pos"], mc["bos"], mc["eos"]) == (2, 1, 4096, 1, 2)
+    assert mc["rope_theta"] == 500000.0
+    g.close()
+    # A file with a Q8_K tensor: the reference's parser throws (ggml_type_block_size has no entry for Q8_K,
+    # quantization.cpp:688-714); tlhost reads it, with the reference's in-memory 290-byte block (quantization.h:111-115),
+    # so that Q8_K matrices can be fed to tl_qweight_upload from a file at all. Documented difference (DESIGN 2).
+    ref_says = json.loads(bytes(g4["q8k_ref_parse_json"]))
+    assert "unknown or unsupported type: 15" in ref_says["error"]
+    path = str(tmp_path / "q8k.gguf")
+    g4["q8k"].tofile(path)
+    g = H.GGUF(path)
+    name, typ, dims, off, raw = g.tensor(g.counts()[0] - 1)
+    assert (name, typ, dims, raw.size) == ("blk.0.extra_q8k.weight", 15, [256, 2], 2 * 290)
+    g.close()
+
+
+def test_reference_parser_still_agrees_with_the_fixture(golden, tmp_path):
+    """Where oracle/_ref is built (the reference's gguf_parser.cpp compiled from /root/reference), re-parse the fixture
+    file with it: the committed JSON is what the reference says today."""
+    import json
+    from oracle.oracle import Ref
+    if not Ref.available():
+        pytest.skip("oracle/_ref/libtlref.so not built")
+    ref = Ref()
+    if not hasattr(ref.L, "ref_gguf_open"):
+        pytest.skip("libtlref.so predates the parser doorway")
+    g4 = golden["g4_gguf"]
+    for tag in ("good", "q8k"):
+        path = str(tmp_path / f"{tag}.gguf")
+        g4[tag].tofile(path)
+        assert ref.gguf_parse(path) == json.loads(bytes(g4[tag + "_ref_parse_json"])), tag
+
+
 def _distribution(logits, temperature, top_k, top_p):
     """numpy restatement of api.cpp:138-210: double softmax of (l - max)/T rounded to float, descending sort by
     (prob, id), top-k cut, float cumulative sum until >= top_p, float renormalisation."""

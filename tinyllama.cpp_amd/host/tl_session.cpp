@@ -67,12 +67,15 @@ ModelConfig config_from_gguf(const GGUFFile& f) {
   c.num_attention_heads = meta_int(f, "llama.attention.head_count", 0);
   c.num_key_value_heads = meta_int(f, "llama.attention.head_count_kv", c.num_attention_heads);
   c.num_hidden_layers = meta_int(f, "llama.block_count", 0);
-  c.max_position_embeddings = meta_int(f, "llama.context_length", 2048);
+  // model_config.cpp:168-177: llama.* with phi.* / mistral.* fallbacks, 4096 when the key is missing, and anything outside
+  // (0, 8192] becomes 2048
+  c.max_position_embeddings =
+      meta_int(f, "llama.context_length", meta_int(f, "phi.context_length", meta_int(f, "mistral.context_length", 4096)));
   if (c.max_position_embeddings <= 0 || c.max_position_embeddings > 8192) c.max_position_embeddings = 2048;
   c.rms_norm_eps = meta_float(f, "llama.attention.layer_norm_rms_epsilon", 1e-5f);
   c.rope_theta = meta_float(f, "llama.rope.freq_base", 10000.0f);
-  c.bos_token_id = meta_int(f, "tokenizer.ggml.bos_token_id", 1);
-  c.eos_token_id = meta_int(f, "tokenizer.ggml.eos_token_id", 2);
+  c.bos_token_id = meta_int(f, "tokenizer.ggml.bos_token_id", -1);  // (-1: no such token, model_config.cpp:199-200)
+  c.eos_token_id = meta_int(f, "tokenizer.ggml.eos_token_id", -1);
   c.architecture = meta_str(f, "general.architecture");
   c.name = meta_str(f, "general.name");
   return c;

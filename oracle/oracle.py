@@ -197,6 +197,21 @@ class Oracle:
         return logits
 
 
+    def sample_candidates(self, logits, temperature, top_k, top_p):
+        """(ids, probs) of sample_top_k_top_p_temperature (api.cpp:126-216) before the draw."""
+        logits = np.ascontiguousarray(logits, np.float32)
+        ids = np.empty(logits.size, np.int32)
+        probs = np.empty(logits.size, np.float32)
+        self.L.tlo_sample_candidates.argtypes = [_fp, C.c_int, C.c_float, C.c_int, C.c_float, _ip, _fp]
+        n = self.L.tlo_sample_candidates(_f(logits), logits.size, temperature, top_k, top_p, ids.ctypes.data_as(_ip), _f(probs))
+        return ids[:n].copy(), probs[:n].copy()
+
+    def discrete_draw(self, probs, u):
+        probs = np.ascontiguousarray(probs, np.float32)
+        self.L.tlo_discrete_draw.argtypes = [_fp, C.c_int, C.c_double]
+        return int(self.L.tlo_discrete_draw(_f(probs), probs.size, float(u)))
+
+
 class OracleModel:
     """A model held by the oracle. `tensors`: dict name -> (type, uint8/float32 ndarray, rows, cols),
     names as in GGUF. Arrays are kept alive here (the C side borrows them)."""

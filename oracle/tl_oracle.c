@@ -464,6 +464,87 @@ void tlo_apply_repetition_penalty(float* logits, int vocab, const int* generated
   }
 }
 
+/* api.cpp:126-216 sample_top_k_top_p_temperature, up to (not including) the random draw: the candidate set in draw
+ * order and its renormalised probabilities. Returns the candidate count; temperature < 0.05 is the greedy branch
+ * (api.cpp:134-136): one candidate, the first maximum, probability 1. ids / probs need room for `vocab` entries.
+ * Order of operations as in the reference: (l - max) * (1/T) in float; exp and the sum in double; /sum in double, then
+ * rounded to float; std::sort with std::greater on (prob, id) pairs, i.e. ties broken towards the HIGHER id; top_k cut;
+ * float running sum until >= top_p; float renormalisation. */
+typedef struct {
+  float p;
+  int id;
+} tlo_prob_id;
+static int tlo_prob_id_greater(const void* a, const void* b) {
+  const tlo_prob_id *x = (const tlo_prob_id*)a, *y = (const tlo_prob_id*)b;
+  if (x->p != y->p) return x->p > y->p ? -1 : 1;
+  if (x->id != y->id) return x->id > y->id ? -1 : 1;
+  return 0;
+}
+int tlo_sample_candidates(const float* logits, int vocab, float temperature, int top_k, float top_p, int* ids,
+                          float* probs) {
+  if (vocab <= 0) return 0;
+  if (temperature < 0.05f) {
+    ids[0] = tlo_argmax(logits, vocab);
+    probs[0] = 1.0f;
+    return 1;
+  }
+  if (top_k > vocab) top_k = vocab;
+  if (top_k <= 0) top_k = vocab;
+  float max_logit = -INFINITY;
+  for (int i = 0; i < vocab; ++i)
+    if (logits[i] > max_logit) max_logit = logits[i]; /* std::max(max_logit, logit) */
+  const float scale = 1.0f / temperature;
+  double* pd = (double*)malloc(sizeof(double) * (size_t)vocab);
+  tlo_prob_id* pi = (tlo_prob_id*)malloc(sizeof(tlo_prob_id) * (size_t)vocab);
+  double sum_exp = 0.0;
+  for (int i = 0; i < vocab; ++i) {
+    const float scaled = (logits[i] - max_logit) * scale;
+    pd[i] = exp((double)scaled);
+    sum_exp += pd[i];
+  }
+  for (int i = 0; i < vocab; ++i) pd[i] = sum_exp > 0.0 ? pd[i] / sum_exp : 1.0 / vocab;
+  for (int i = 0; i < vocab; ++i) {
+    pi[i].p = (float)pd[i];
+    pi[i].id = i;
+  }
+  qsort(pi, (size_t)vocab, sizeof(tlo_prob_id), tlo_prob_id_greater); /* a total order: any sort gives std::sort's result */
+  int n = top_k < vocab ? top_k : vocab;
+  float cumulative = 0.0f;
+  int last = 0;
+  for (int i = 0; i < n; ++i) {
+    cumulative += pi[i].p;
+    last = i;
+    if (cumulative >= top_p) break;
+  }
+  n = last + 1;
+  float final_sum = 0.0f;
+  for (int i = 0; i < n; ++i) final_sum += pi[i].p;
+  for (int i = 0; i < n; ++i) {
+    ids[i] = pi[i].id;
+    probs[i] = final_sum > 0.0f ? pi[i].p / final_sum : 1.0f / (float)n;
+  }
+  free(pd);
+  free(pi);
+  return n;
+}
+
+/* The draw of std::discrete_distribution<int> (api.cpp:211-213) as libstdc++ 11 implements it (bits/random.tcc:2656-2713):
+ * weights summed and normalised in double, partial sums, the last forced to 1, then the FIRST index whose cumulative
+ * probability is >= u (std::lower_bound) for u = generate_canonical<double> in [0, 1). A single weight always draws 0.
+ * (The reference seeds its std::mt19937 from std::random_device, so u itself is not reproducible.) */
+int tlo_discrete_draw(const float* probs, int n, double u) {
+  if (n < 2) return 0;
+  double sum = 0.0;
+  for (int i = 0; i < n; ++i) sum += (double)probs[i];
+  double cp = 0.0;
+  for (int i = 0; i < n; ++i) {
+    cp += (double)probs[i] / sum;
+    const double c = i == n - 1 ? 1.0 : cp;
+    if (c >= u) return i;
+  }
+  return n - 1;
+}
+
 /* ------------------------------------------------------------------------------------------
  * model-level
  * ---------------------------------------------------------------------------------------- */

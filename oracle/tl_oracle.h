@@ -85,6 +85,13 @@ int tlo_argmax(const float* v, int n);
 void tlo_apply_repetition_penalty(float* logits, int vocab, const int* generated, int n_generated,
                                   float penalty, int window);
 
+/* sample_top_k_top_p_temperature (api.cpp:126-216) without the draw: candidate ids in draw order + renormalised
+ * probabilities (room for `vocab` entries each); returns their count. temperature < 0.05: the greedy branch. */
+int tlo_sample_candidates(const float* logits, int vocab, float temperature, int top_k, float top_p, int* ids,
+                          float* probs);
+/* std::discrete_distribution's draw for a uniform u in [0,1) (libstdc++ bits/random.tcc:2656-2713) */
+int tlo_discrete_draw(const float* probs, int n, double u);
+
 /* ---- model-level --------------------------------------------------------------------- */
 typedef struct tlo_model tlo_model;
 

@@ -162,6 +162,36 @@ def _distribution(logits, temperature, top_k, top_p):
     return np.array(order, np.int32), np.array([p[i] / tot for i in order], np.float32)
 
 
+def test_host_sampler_matches_the_oracle(H, oracle):
+    """The product's host port of sample_top_k_top_p_temperature (host/tl_session.cpp) against the oracle's independent
+    restatement of api.cpp:126-216 (oracle/tl_oracle.c): both run glibc's exp in double, so ids AND probabilities must be
+    identical bit for bit; the numpy restatement above is a third reading. Parity unpinned (api.cpp needs Boost; the
+    reference holds no sampling vectors)."""
+    rng = np.random.default_rng(3)
+    for V, T, k, pp in ((1000, 0.8, 40, 0.9), (257, 1.5, 0, 0.5), (64, 0.1, 5, 0.99), (5000, 1.0, 5000, 1.0),
+                        (100, 0.7, 1000, 0.0), (128256, 0.7, 40, 0.9), (300, 0.01, 40, 0.9), (50, 1.0, -3, 1.0)):
+        logits = (rng.standard_normal(V) * 3).astype(np.float32)
+        logits[3] = logits[7] = logits[11]
+        oi, op = oracle.sample_candidates(logits, T, k, pp)
+        if T < 0.05:  # greedy branch: one candidate, the first maximum
+            assert oi.tolist() == [int(np.argmax(logits))] and op.tolist() == [1.0]
+            continue
+        ids, probs = H.sampling_distribution(logits, T, k, pp)
+        assert np.array_equal(ids, oi), (V, T, k, pp)
+        assert np.array_equal(probs.view(np.uint32), op.view(np.uint32)), (V, T, k, pp)
+        wi, wp = _distribution(logits, T, k, pp)
+        assert np.array_equal(oi, wi) and np.allclose(op, wp, rtol=1e-6, atol=0)
+    # all logits -inf except none: exp underflow everywhere but the maximum
+    spike = np.full(400, -80.0, np.float32)
+    spike[17] = 30.0
+    oi, op = oracle.sample_candidates(spike, 1.0, 40, 0.9)
+    assert oi.tolist() == [17] and op.tolist() == [1.0]
+    # std::discrete_distribution's draw: first index whose cumulative probability (double) reaches u
+    p = np.array([0.5, 0.25, 0.25], np.float32)
+    assert [oracle.discrete_draw(p, u) for u in (0.0, 0.49, 0.5, 0.5000001, 0.75, 0.76, 0.999999)] == [0, 0, 0, 1, 1, 2, 2]
+    assert oracle.discrete_draw(p[:1], 0.9) == 0
+
+
 def test_sampler_pieces_match_restatement(H):
     rng = np.random.default_rng(0)
     for V, T, k, pp in ((1000, 0.8, 40, 0.9), (257, 1.5, 0, 0.5), (64, 0.1, 5, 0.99), (5000, 1.0, 5000, 1.0),

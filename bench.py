@@ -380,10 +380,64 @@ def cpu_baseline(cfg, keep, n_layers, w_bytes):
     L = cfg["n_layers"]
     t_tok = t_cold * max(L - 2, 0) + t_warm * min(L, 2) + t_tail
     om.close()
-    return {"value": round(1.0 / t_tok, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
+    port = {"value": round(1.0 / t_tok, 4), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{n_layers} of {cfg['n_layers']} layers x 2 tokens + lm_head, scaled to full depth; "
                       "reference structure (per-token whole-tensor dequant, Kahan-double mat-vec, l-2 eviction)",
             "s_per_token": round(t_tok, 3), "gbps": round(w_bytes / t_tok / 1e9, 3)}
+    ref = reference_cpu_baseline(cfg, keep, w_bytes, threads)
+    if ref is None:  # oracle/_ref did not travel: the port alone, with the ratio measured in the build container
+        port["port_vs_reference"] = PORT_VS_REFERENCE_MEASURED
+        port["port_vs_reference_source"] = "profiles/r02_c_cpu_baseline_validation.json (build container, 8 threads)"
+        return port
+    ref["port_value"] = port["value"]
+    ref["port_vs_reference"] = round(port["value"] / ref["value"], 3)
+    return ref
+
+
+PORT_VS_REFERENCE_MEASURED = 1.6  # tools/validate_cpu_baseline.py, q4_k 14336x4096, best of several runs: 1.46-1.72
+
+
+def reference_cpu_baseline(cfg, keep, w_bytes, threads):
+    """The same per-token cost from the REFERENCE'S OWN compiled functions (oracle/_ref/libtlref.so, built from its
+    quantization.cpp + utils.cpp): dequantize_vector_*_to_f32 then matvec_f32_f32_vector_cpu on each of layer 0's seven
+    projection tensors (what ensure_*_dequantized + the projections of TinyLlamaModel::forward cost per layer and
+    token) and on lm_head, composed as forward composes them: (L-2) layers pay dequantize + mat-vec, the two layers that
+    keep their FP32 copy and lm_head pay the mat-vec only. Attention, norms, RoPE and SwiGLU (< 1 % of the port's time at
+    this position) are left out, which flatters the reference slightly. None when the library is not there."""
+    try:
+        from oracle.oracle import Ref
+        ref = Ref()
+        if not ref.can_time():
+            return None
+    except Exception:
+        return None
+    rng = np.random.default_rng(7)
+    deq = mv = 0.0
+    used = []
+    for name, (typ, arr, rows, cols) in keep.items():
+        if not (name.startswith("blk.0.") or name == "output.weight") or arr.dtype != np.uint8:
+            continue
+        x = rng.standard_normal(cols).astype(np.float32)
+        try:
+            d, m, _ = ref.time_dequant_matvec(typ, arr, x, rows, cols, reps=1)
+        except AssertionError:
+            return None  # a format the reference has no whole-tensor dequantizer for
+        if name == "output.weight":
+            t_head = m
+        else:
+            deq, mv = deq + d, mv + m
+        used.append(name)
+    if "output.weight" not in used or len(used) < 2:
+        return None
+    L = cfg["n_layers"]
+    t_tok = (deq + mv) * max(L - 2, 0) + mv * min(L, 2) + t_head
+    return {"value": round(1.0 / t_tok, 4), "unit": "tokens/s", "cores": threads, "kind": "reference",
+            "sample": "the reference's own dequantize_vector_*_to_f32 + matvec_f32_f32_vector_cpu (oracle/_ref, compiled "
+                      f"from its sources) on layer 0's {len(used) - 1} projection tensors and lm_head, composed per token "
+                      "as its forward does: (L-2) x (dequantize + mat-vec) + 2 x mat-vec + lm_head mat-vec; "
+                      "attention/norm/rope not included",
+            "s_per_token": round(t_tok, 3), "gbps": round(w_bytes / t_tok / 1e9, 3),
+            "layer_dequant_s": round(deq, 3), "layer_matvec_s": round(mv, 3), "lm_head_matvec_s": round(t_head, 3)}
 
 
 if __name__ == "__main__":

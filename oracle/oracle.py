@@ -337,8 +337,8 @@ class Ref:
             L.ref_gguf_tensor_bytes.argtypes = [C.c_long, C.c_void_p, C.c_size_t]
             L.ref_gguf_meta.argtypes = [C.c_long, C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong),
                                         C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.c_char_p, C.c_size_t]
-            L.ref_time_q4k_dequant_matvec.argtypes = [C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double),
-                                                      C.POINTER(C.c_double)]
+            L.ref_time_dequant_matvec.argtypes = [C.c_int, C.c_void_p, _fp, _fp, C.c_int, C.c_int, C.c_int,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
 
     def gguf_parse(self, path, use_mmap=True):
         """The file as the reference's load_gguf_meta (gguf_parser.cpp:123) sees it: {"alignment", "tensors": [dict],
@@ -370,14 +370,17 @@ class Ref:
         L.ref_gguf_close()
         return out
 
-    def time_q4k_dequant_matvec(self, blocks, x, rows, cols, reps=3):
-        """(dequantize seconds, mat-vec seconds, y): the reference's dequantize_vector_q4k_to_f32 +
+    def can_time(self):
+        return hasattr(self.L, "ref_time_dequant_matvec")
+
+    def time_dequant_matvec(self, typ, blocks, x, rows, cols, reps=3):
+        """(dequantize seconds, mat-vec seconds, y): the reference's dequantize_vector_*_to_f32 +
         matvec_f32_f32_vector_cpu on one tensor, best of `reps`, timed inside the library (no marshalling copies)."""
         blocks = np.ascontiguousarray(blocks)
         x = np.ascontiguousarray(x, np.float32)
         y = np.empty(rows, np.float32)
         d, m = C.c_double(), C.c_double()
-        assert self.L.ref_time_q4k_dequant_matvec(_v(blocks), _f(x), _f(y), rows, cols, reps, C.byref(d), C.byref(m)) == 0
+        assert self.L.ref_time_dequant_matvec(typ, _v(blocks), _f(x), _f(y), rows, cols, reps, C.byref(d), C.byref(m)) == 0
         return d.value, m.value, y
 
     def fp16_to_fp32_bits(self, h, is_scale=False):

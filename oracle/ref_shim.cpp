@@ -278,19 +278,22 @@ int ref_gguf_meta(long i, char* key, size_t key_len, int* kind, unsigned long lo
 }
 
 // ---- timing of the reference's own decode-path pair on one tensor, with no marshalling inside the timed region ------
-// dequantize_vector_q4k_to_f32 (quantization.cpp:1054; what ensure_*_dequantized runs once per token and tensor,
-// weight_management.cpp:44-196) followed by matvec_f32_f32_vector_cpu (utils.cpp:349): seconds of each, best of `reps`.
-int ref_time_q4k_dequant_matvec(const void* blocks, const float* x, float* y, int rows, int cols, int reps, double* dequant_s,
-                                double* matvec_s) {
-  const size_t nblocks = (size_t)rows * cols / GGML_QK_K;
-  const std::vector<block_q4_K> b = as_blocks<block_q4_K>(blocks, nblocks);
+// dequantize_vector_q{4k,6k,8_0}_to_f32 (quantization.cpp:1054-1223; what ensure_*_dequantized runs once per token and
+// tensor, weight_management.cpp:44-196) followed by matvec_f32_f32_vector_cpu (utils.cpp:349): seconds of each, best of
+// `reps`. Returns -1 for a type the reference has no whole-tensor dequantizer for.
+}  // extern "C" (the helper below is a template)
+namespace {
+template <class B, class F>
+int time_pair(const void* blocks, size_t nblocks, size_t block_elems, const float* x, float* y, int rows, int cols, int reps,
+              double* dequant_s, double* matvec_s, F dequant) {
+  const std::vector<B> b = as_blocks<B>(blocks, nblocks);
   const std::vector<float> xv(x, x + cols);
   std::vector<float> out;
   double best_d = 1e30, best_m = 1e30;
   for (int r = 0; r < reps; ++r) {
     std::vector<float> w;  // a fresh vector per repetition, as after clear_layer_dequantized_weights
     const auto t0 = std::chrono::steady_clock::now();
-    dequantize_vector_q4k_to_f32(b, w, nblocks * GGML_QK_K, 0);
+    dequant(b, w, nblocks * block_elems, 0);
     const auto t1 = std::chrono::steady_clock::now();
     matvec_f32_f32_vector_cpu(w, xv, out, rows, cols);
     const auto t2 = std::chrono::steady_clock::now();
@@ -302,6 +305,25 @@ int ref_time_q4k_dequant_matvec(const void* blocks, const float* x, float* y, in
   *dequant_s = best_d;
   *matvec_s = best_m;
   return 0;
+}
+}  // namespace
+
+extern "C" {
+int ref_time_dequant_matvec(int type, const void* blocks, const float* x, float* y, int rows, int cols, int reps,
+                            double* dequant_s, double* matvec_s) {
+  const size_t n = (size_t)rows * cols;
+  switch (type) {
+    case GGML_TYPE_Q4_K:
+      return time_pair<block_q4_K>(blocks, n / GGML_QK_K, GGML_QK_K, x, y, rows, cols, reps, dequant_s, matvec_s,
+                                   dequantize_vector_q4k_to_f32);
+    case GGML_TYPE_Q6_K:
+      return time_pair<block_q6_K>(blocks, n / GGML_QK_K, GGML_QK_K, x, y, rows, cols, reps, dequant_s, matvec_s,
+                                   dequantize_vector_q6k_to_f32);
+    case GGML_TYPE_Q8_0:
+      return time_pair<block_q8_0>(blocks, n / GGML_QK8_0, GGML_QK8_0, x, y, rows, cols, reps, dequant_s, matvec_s,
+                                   dequantize_vector_q8_0_to_f32);
+    default: return -1;
+  }
 }
 
 }  // extern "C"

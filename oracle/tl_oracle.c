@@ -659,6 +659,15 @@ void tlo_lookup_embedding(tlo_model* m, int token, float* out) {
   tlo_dequantize(t->type, (const uint8_t*)t->data + (size_t)token * bpr * bb, bpr, out);
 }
 
+/* dequantize_vector_q{4k,6k,8_0}_to_f32 (quantization.cpp:1054-1223) in the reference's structure, for the CPU baseline:
+ * f32_weights.resize(n) value-initialises the fresh vector (a pass of zeros over the whole FP32 tensor) before the serial
+ * block loop fills it. Same values as tlo_dequantize; the extra pass is part of what the reference pays per tensor and
+ * token (tools/validate_cpu_baseline.py times this against the reference's own function). */
+void tlo_dequantize_whole_tensor(int type, const void* blocks, size_t nblocks, float* out) {
+  memset(out, 0, nblocks * tlo_type_block_elems(type) * sizeof(float));
+  tlo_dequantize(type, blocks, nblocks, out);
+}
+
 /* one projection y = W x through either the fused path or (ref_structure) ensure_*_dequantized +
  * matvec_f32_f32_vector_cpu — the two are bit-identical */
 static void project(tlo_model* m, tlo_tensor* t, const float* x, float* y) {
@@ -666,7 +675,7 @@ static void project(tlo_model* m, tlo_tensor* t, const float* x, float* y) {
     if (!t->f32) {
       const size_t n = (size_t)t->rows * t->cols;
       t->f32 = (float*)malloc(n * sizeof(float));
-      tlo_dequantize(t->type, t->data, n / tlo_type_block_elems(t->type), t->f32);
+      tlo_dequantize_whole_tensor(t->type, t->data, n / tlo_type_block_elems(t->type), t->f32);
     }
     tlo_matvec_f32(t->f32, x, y, t->rows, t->cols);
   } else {
@@ -679,7 +688,7 @@ static void project_batch(tlo_model* m, tlo_tensor* t, const float* x, float* y,
     if (!t->f32) {
       const size_t n = (size_t)t->rows * t->cols;
       t->f32 = (float*)malloc(n * sizeof(float));
-      tlo_dequantize(t->type, t->data, n / tlo_type_block_elems(t->type), t->f32);
+      tlo_dequantize_whole_tensor(t->type, t->data, n / tlo_type_block_elems(t->type), t->f32);
     }
     tlo_matmul_q_batch(TLO_F32, t->f32, x, y, T, t->rows, t->cols);
   } else {

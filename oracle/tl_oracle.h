@@ -49,6 +49,8 @@ size_t tlo_type_block_elems(int type); /* quantization.cpp:688-717 (Q8_K: 256 he
 
 /* nblocks blocks -> nblocks*block_elems floats */
 void tlo_dequantize(int type, const void* blocks, size_t nblocks, float* out);
+/* the same values in the reference's whole-tensor structure (zero-filled fresh vector, then the serial block loop) */
+void tlo_dequantize_whole_tensor(int type, const void* blocks, size_t nblocks, float* out);
 /* quantize_fp32_to_q8_K, quantization.cpp:719-770 (290-byte blocks, fp16 d) */
 void tlo_quantize_q8_k(const float* x, size_t n, void* blocks_out);
 

@@ -163,6 +163,8 @@ def main():
             if want_cpu and (layer < 0 or layer < args.cpu_layers):
                 keep[name] = (typ, arr, rows, cols)
             del arr
+        if tp_size > 1 and dist is not None:
+            dist.barrier()  # finalize runs one step, exchanges included: the ranks must enter it together (uploads skew)
         model.finalize()
         return model
 

@@ -7,7 +7,7 @@
  *   - plain C: pointers and sizes only. `void* stream` is a hipStream_t (NULL = the default stream),
  *     the counterpart of the reference's `cudaStream_t stream = 0` arguments.
  *   - every function returns int: 0 = ok, non-zero = error; tl_last_error() gives the text. The C++ host
- *     shim (tinyllama.cpp_amd/host/tl_backend.hpp) turns non-zero into std::runtime_error, which is the
+ *     layer (tinyllama.cpp_amd/host/tl_session.cpp:14-16, `check`) turns non-zero into std::runtime_error, which is the
  *     reference's convention (gpuErrchk, cuda_kernels.h:66-82). Argument-validation failures return an
  *     error instead of the reference's log-and-return-silently (cuda_kernels.cu:1335-1351).
  *   - `*_dev` pointers are device pointers BORROWED from the caller; `*_host` are host pointers borrowed
@@ -38,11 +38,13 @@ typedef struct tl_model tl_model;     /* a whole model + KV cache + workspaces +
 /* ---- runtime: replaces the inline cudaSetDevice/cudaMalloc/cudaMemcpy/cudaFree/cudaStream*/
 /*      cublasCreate sites (215 of them) ---------------------------------------- */
 const char* tl_last_error(void);
+/* hipSetDevice + sanity (gfx950 expected) + this device's address of the static no-allocation workspace
+ * (tl_attention_noalloc); call once per device the process uses, with that device's ordinal */
 int tl_init(int device_ordinal);
 /* frees the workspaces that the operator-level entry points (tl_attention, tl_matmul_q, tl_sample_top_k_top_p) grow
  * lazily per device; optional (the process exit frees them too). Those entry points share one workspace per device:
  * calls that overlap on one device must be serialised by the caller (one host thread, as in the reference). */
-int tl_shutdown(void);              /* hipSetDevice + sanity (gfx950 expected) */
+int tl_shutdown(void);
 int tl_device_count(int* count_out);
 int tl_malloc(void** dev_out, size_t bytes);  /* cudaMalloc sites e.g. gpu_initialization.cpp:91-531 */
 int tl_free(void* dev);
@@ -73,7 +75,7 @@ int tl_quantize_q8_k(const float* x_dev, size_t n, void* blocks_dev, void* strea
 
 /* y[rows] = W x : replaces matvec_f32_f32_cuda (cuda_kernels.h:171) / matvec_bf16_f32_cuda (:424), on the
  * quantized weights directly. FP32 accumulate; tolerance vs the reference's Kahan-double CPU dot is stated
- * in tests/test_gpu_gemv.py. */
+ * in tests/test_gpu_parity.py (test_gemv_golden, test_gemv_vs_oracle_model_shapes). */
 int tl_matvec_q(const tl_qweight* w, const float* x_dev, float* y_dev, void* stream);
 /* Y[T][rows] = X[T][cols] W^T : replaces gemm_f32_f32_cuda / gemm_f32_to_bf16_f32_cuda via
  * smart_gemm_batch_cuda (model.cpp:2141-2249) for batched prefill. */

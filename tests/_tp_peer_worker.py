@@ -25,8 +25,30 @@ def main():
     if not linked:
         print(f"rank {rank}: peer link refused: {E.lib().tl_last_error().decode(errors='replace')}")
         return 3
+    mode = sys.argv[6] if len(sys.argv) > 6 else ""
+    if mode in ("rank1-late", "rank1-late-barrier"):
+        # rank 1 arrives 1.5 s late at finalize, whose warm-up step is a collective of the group. Without a host barrier
+        # rank 0 waits in vain and tl_model_finalize must SAY so (error 5), not leave a stale flag behind; with the
+        # barrier (what bench.py and tools/peer_latency.py do) everything is as if nobody had been late.
+        import time
+        for name, (typ, arr, rows, cols) in tensors.items():
+            m.set_tensor(name, typ, arr, rows, cols)
+        if rank == 1:
+            time.sleep(1.5)
+        if mode == "rank1-late-barrier":
+            rv.agree(True)
+        outcome, logits = "ok", np.zeros(1, np.float32)
+        try:
+            m.finalize()
+            logits = m.decode(3, 0)[0]
+        except E.capi.TlError as e:
+            outcome = str(e)
+        np.savez(os.path.join(workdir, f"result_{rank}.npz"), linked=True, outcome=outcome, logits=logits)
+        rv.agree(True)
+        m.free()
+        return 0
     m.load(tensors)
-    if len(sys.argv) > 6 and sys.argv[6] == "rank1-absent":
+    if mode == "rank1-absent":
         # rank 1 stays linked and mapped but never steps: rank 0's exchange must give up at its deadline and the call
         # must return an error (no hang), after which both ranks leave together
         outcome = "n/a"

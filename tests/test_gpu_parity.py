@@ -183,7 +183,8 @@ def test_rope_table_upload_matches_oracle(E, oracle):
 
 
 @pytest.mark.parametrize("nh,nkv,hd,npos", [(4, 2, 64, 1), (32, 4, 64, 77), (32, 8, 128, 300), (8, 8, 128, 2048),
-                                            (64, 8, 128, 700), (32, 4, 64, 1500), (24, 8, 128, 33)])
+                                            (64, 8, 128, 700), (32, 4, 64, 1500), (24, 8, 128, 33),
+                                            (32, 8, 128, 8192), (64, 8, 128, 8192)])
 def test_attention_decode_and_prefill(E, oracle, nh, nkv, hd, npos):
     from tinyllama_cpp_amd.capi import lib, check
     rng = np.random.default_rng(nh + npos)
@@ -343,6 +344,28 @@ def test_model_llama32_3b_shape_two_layers(E, pkg, oracle, mix):
     for pos, tok in enumerate(prompt):
         logits, _ = m.decode(tok, pos)
     assert close(logits, want_logits[0], LOGIT_TOL).all(), np.abs(logits - want_logits[0]).max()
+    m.free()
+    om.close()
+
+
+def test_token_outside_the_vocabulary_embeds_as_zeros(E, pkg, oracle):
+    """lookup_embedding returns a zero vector for an id outside the table (model_utils.cpp:15-19) and the forward pass
+    carries on from it: the decode route (graph step) and the batched prefill route must do the same."""
+    cfg, tensors = pkg.synth.build_model("tiny-gqa", "q4_k_m", seed=3)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    zero = np.zeros(cfg["hidden"], np.float32)
+    bad = cfg["vocab"] + 7
+    toks = np.random.default_rng(4).integers(0, cfg["vocab"], 12).astype(np.int32)
+    toks[5] = bad
+    embed = lambda t: zero if t >= cfg["vocab"] else om.lookup_embedding(int(t))
+    om.reset_kv()
+    want = np.stack([om.forward(embed(t), pos)[1] for pos, t in enumerate(toks)])
+    got = np.stack([m.decode(int(t), pos)[0] for pos, t in enumerate(toks)])
+    assert close(got, want, LOGIT_TOL).all(), np.abs(got - want).max()
+    m.reset_kv()
+    _, allb = m.prefill(toks, 0, all_logits=True)  # 12 tokens >= prefill_min_batch: the MFMA route
+    assert close(allb, want, LOGIT_TOL).all(), np.abs(allb - want).max()
     m.free()
     om.close()
 

@@ -90,6 +90,25 @@ def test_missing_rank_is_an_error_not_a_hang(tmp_path):
     assert "timed out" in str(r0["outcome"]), r0["outcome"]
 
 
+def test_late_rank_at_finalize_is_reported(tmp_path):
+    """Rank 1 reaches tl_model_finalize 1.5 s after rank 0 with a 300 ms poll deadline: the warm-up step's exchange gives up
+    and finalize returns the error instead of leaving the flag for the first decode to trip over."""
+    procs, outs = _run_workers(tmp_path, 2, "tiny-gqa", "q4_k_m", extra=("rank1-late",),
+                               env_extra={"TL_TP_PEER_TIMEOUT_MS": "300"})
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(outs)
+    r0 = dict(np.load(os.path.join(tmp_path, "result_0.npz")))
+    assert "tl_model_finalize" in str(r0["outcome"]) and "timed out" in str(r0["outcome"]), r0["outcome"]
+
+
+def test_late_rank_behind_a_host_barrier_is_fine(tmp_path):
+    procs, outs = _run_workers(tmp_path, 2, "tiny-gqa", "q4_k_m", extra=("rank1-late-barrier",),
+                               env_extra={"TL_TP_PEER_TIMEOUT_MS": "300"})
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(outs)
+    res = [dict(np.load(os.path.join(tmp_path, f"result_{r}.npz"))) for r in range(2)]
+    assert all(str(r["outcome"]) == "ok" for r in res), [str(r["outcome"]) for r in res]
+    assert res[0]["logits"].size > 1 and np.array_equal(res[0]["logits"], res[1]["logits"])
+
+
 def test_import_rejects_garbage_handles(pkg):
     from tinyllama_cpp_amd import engine as E
     from tinyllama_cpp_amd.capi import TlError

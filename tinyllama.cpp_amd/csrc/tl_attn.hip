@@ -283,20 +283,12 @@ int launch_hg(const AttnArgs& a, bool fuse, hipStream_t s) {
   const size_t lds = sizeof(float) * ((size_t)G * HD + 2 * HD + 64 + (size_t)ATT_NW * G * (HD + 4));
   const dim3 grid(a.nkv, TL_ATTN_MAX_SPLITS, (a.nh / a.nkv) / G);
   if (fuse) {
-    static bool attr = false;
-    if (!attr) {
-      TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_split_kernel<HD, G, true>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
+    static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+    TL_TRY(tl_raise_lds_limit(attn_decode_split_kernel<HD, G, true>, 160 * 1024, lds_raised));
     attn_decode_split_kernel<HD, G, true><<<grid, ATT_THREADS, lds, s>>>(a);
   } else {
-    static bool attr = false;
-    if (!attr) {
-      TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_split_kernel<HD, G, false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr = true;
-    }
+    static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+    TL_TRY(tl_raise_lds_limit(attn_decode_split_kernel<HD, G, false>, 160 * 1024, lds_raised));
     attn_decode_split_kernel<HD, G, false><<<grid, ATT_THREADS, lds, s>>>(a);
   }
   TL_HIP(hipGetLastError());

@@ -999,17 +999,7 @@ static bool ksplit_enabled() {
   }
   return on != 0;
 }
-static int gemm_num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            ? prop.multiProcessorCount
-            : 256;
-  }
-  return n;
-}
+static int gemm_num_cus() { return tl_num_cus(); }
 // the workspace of a stream's K-split GEMMs: launches of one stream are ordered, launches of different streams (q | k, v
 // and gate | up run side by side) must not share one. Eight slots; a ninth stream takes over the slot used longest
 // ago after a device-wide sync (streams of freed models leave their slots behind); -1 only if that sync fails.
@@ -1044,12 +1034,8 @@ template <int TYPE, int NP, int NT, int BM>
 int launch_gemm_inst(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
   const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + GB_N - 1) / GB_N;
   constexpr size_t lds = gemm_lds_bytes<NP, BM>();
-  static bool attr = false;  // per instantiation
-  if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_kernel<TYPE, NP, NT, BM>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_q_kernel<TYPE, NP, NT, BM>, (int)lds, lds_raised));
   gemm_q_kernel<TYPE, NP, NT, BM><<<dim3(mtiles * ntiles), dim3(GEMM_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
   TL_HIP(hipGetLastError());
   return 0;
@@ -1059,12 +1045,8 @@ template <int TYPE, int NP, int NT, int BM, int BN>
 int launch_gemm_ws_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
   const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + BN - 1) / BN;
   constexpr size_t lds = (size_t)2 * NP * (BM + BN) * LROW * sizeof(__bf16);
-  static bool attr = false;
-  if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_q_ws_kernel<TYPE, NP, NT, BM, BN>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_q_ws_kernel<TYPE, NP, NT, BM, BN>, (int)lds, lds_raised));
   // Skinny problems (few token panels: the multi-sequence decode step, short prompts) have fewer tiles than the chip has
   // workgroup slots (2 per CU): split K over up to 8 slices so that every CU streams weights, partial tiles into a
   // per-stream workspace, summed in slice order (deterministic) with the residual by one small kernel.
@@ -1114,12 +1096,8 @@ template <int TYPE, int NPX, int BN, int BM>
 int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
   const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + BN - 1) / BN;
   constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
-  static bool attr = false;
-  if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_qi_ws_kernel<TYPE, NPX, BN, BM>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_qi_ws_kernel<TYPE, NPX, BN, BM>, (int)lds, lds_raised));
   const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
   const int tpad = (int)tl_gemm_padded_tokens(T);
   const int tiles = mtiles * ntiles, nk_all = w.cols / GB_K;

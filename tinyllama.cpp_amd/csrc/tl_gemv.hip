@@ -595,12 +595,8 @@ static int g_num_cus = 256;
 static int g_max_waves = 16;
 
 static int gemv_setup() {
+  g_num_cus = tl_num_cus();  // of the CURRENT device (cached per ordinal): a process may drive unlike devices
   if (g_gemv_setup_done) return 0;
-  int dev = 0;
-  TL_HIP(hipGetDevice(&dev));
-  hipDeviceProp_t prop;
-  TL_HIP(hipGetDeviceProperties(&prop, dev));
-  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("TL_GEMV_WAVES")) {  // tuning knob (experiments only)
     const int w = atoi(e);
     if (w >= 1 && w <= 16) g_max_waves = w;
@@ -621,12 +617,8 @@ struct Launch {
 
 template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0>
 static int gemv_launch_ra(const Launch& L, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA>, 160 * 1024, lds_raised));
   gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], L.v, L.t[0],
                                                                                L.t[1], L.t[2], L.nsegA, L.wavesA);
   return 0;
@@ -1171,12 +1163,8 @@ __global__ __launch_bounds__(NV <= 2 ? GEMV_MAX_THREADS : GEMV_MAX_THREADS / 2) 
 
 template <int TYPE, int NV, int MODE>
 static int gemv_nv_launch_inst(const Launch& L, const NvVec& v, int nseg, hipStream_t s) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemv_nv_kernel<TYPE, NV, MODE>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_done = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemv_nv_kernel<TYPE, NV, MODE>, 160 * 1024, lds_raised));
   gemv_nv_kernel<TYPE, NV, MODE><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], v, L.t[0], L.t[1], L.t[2], nseg);
   return 0;
 }

@@ -29,6 +29,35 @@ void tl_set_error(const char* fmt, ...);
     if (rc_ != 0) return rc_; \
   } while (0)
 
+// hipFuncSetAttribute is per DEVICE (every device has its own copy of the code object): remember it per device ordinal,
+// not per process, so that a process driving several GPUs raises the LDS limit on each of them. `done` is the call
+// site's own static mask (one per kernel instantiation).
+struct TlDeviceOnce {
+  unsigned long long mask[2] = {0, 0};  // ordinals 0..127
+};
+template <class K>
+static inline int tl_raise_lds_limit(K kernel, int bytes, TlDeviceOnce& done) {
+  int dev = 0;
+  TL_HIP(hipGetDevice(&dev));
+  TL_REQUIRE(dev >= 0 && dev < 128, "device ordinal %d out of range", dev);
+  unsigned long long& m = done.mask[dev >> 6];
+  if (m >> (dev & 63) & 1ull) return 0;
+  TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  m |= 1ull << (dev & 63);
+  return 0;
+}
+// CU count of the current device (cached per ordinal)
+static inline int tl_num_cus() {
+  static int cus[128] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 128) return 256;
+  if (!cus[dev]) {
+    int n = 0;
+    cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+  }
+  return cus[dev];
+}
+
 // lazily grown per-(device, slot) workspace of the operator-level entry points (tl_runtime.hip)
 enum TlScratchSlot {
   TL_SCRATCH_ATTN = 0,
@@ -189,6 +218,7 @@ int tl_peer_selftest(TlPeer* p, hipStream_t s, int* ok_out);
 int tl_peer_all_reduce(TlPeer* p, const float* in, float* out, hipStream_t s);
 int tl_peer_all_gather(TlPeer* p, float* buf, hipStream_t s);
 int tl_peer_error_async(TlPeer* p, unsigned* flag_host, hipStream_t s);
+int tl_peer_clear_error(TlPeer* p, hipStream_t s);  // the flag is sticky until cleared
 void tl_peer_destroy(TlPeer* p);
 
 // ---- tl_batch.hip: position-dependent kernels of the multi-sequence decode step (sequence-major KV cache) ------------

@@ -504,6 +504,9 @@ static int tp_check_peer(tl_model* m) {
   TL_TRY(tl_peer_error_async(m->peer, &flag, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
   if (flag != 0) {
+    // the flag is sticky on the device: clear it, so that the NEXT call reports its own exchanges, not this one's
+    TL_TRY(tl_peer_clear_error(m->peer, m->stream));
+    TL_HIP(hipStreamSynchronize(m->stream));
     tl_set_error("tl_model: a peer-to-peer exchange timed out waiting for another rank of the tensor-parallel group");
     return 5;
   }
@@ -512,7 +515,9 @@ static int tp_check_peer(tl_model* m) {
 
 // ---- the step in pieces, so that a group of shards living in ONE process can be driven in lockstep (tests) ------------
 static int enqueue_embed(tl_model* m, hipStream_t s) {
-  return tl_launch_dequant_rows(m->tok, m->state, 0, 1, m->x, s);
+  // gather form: a token id outside the table embeds as a zero vector, as lookup_embedding does (model_utils.cpp:15-19)
+  // and as the prefill route (prefill_embed) does, instead of silently reading row 0
+  return tl_launch_dequant_gather(m->tok, m->state, 1, m->x, s);
 }
 // norm + QKV GEMV, RoPE + KV write + attention, attn_output GEMV (-> x, or the partial xp when tp > 1)
 static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
@@ -798,10 +803,19 @@ extern "C" int tl_model_finalize(tl_model* m) {
     m->finalized = true;
     return 0;
   }
-  // one eager step (position 0) outside capture: sets kernel attributes and validates every launch
+  // one eager step (position 0) outside capture: sets kernel attributes and validates every launch. With the peer
+  // exchange on, this step is a COLLECTIVE: every rank of the group must reach tl_model_finalize within the poll deadline
+  // (TL_TP_PEER_TIMEOUT_MS, 5 s by default) of the others; put a host barrier before it (bench.py does). A rank that
+  // waited in vain gets error 5 here and the group is out of step for good: free the models of all ranks.
+  if (m->peer_on) TL_TRY(tl_peer_clear_error(m->peer, m->stream));
   TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));
   TL_TRY(enqueue_step(m));
   TL_HIP(hipStreamSynchronize(m->stream));
+  if (tp_check_peer(m) != 0) {
+    tl_set_error("tl_model_finalize: the warm-up step's peer-to-peer exchange timed out: the ranks of a tensor-parallel "
+                 "group must call tl_model_finalize together (host barrier first); free this group's models");
+    return 5;
+  }
   if (const char* e = getenv("TL_NO_GRAPH")) m->no_graph = atoi(e) != 0;
   if (!m->no_graph) {  // capture the step once
     TL_HIP(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));

@@ -289,12 +289,8 @@ int tl_launch_attn_decode(const float* q, const float* kc, const float* vc, floa
   const int cap = pos_dev ? max_seq : seq_len;  // LDS sized for the longest possible sequence under a graph
   const size_t lds = sizeof(float) * (32 + 4 * (size_t)hd + (size_t)cap);
   TL_REQUIRE(lds <= 160 * 1024, "attention: sequence length %d needs %zu B of LDS (> 160 KiB)", cap, lds);
-  static bool attr = false;
-  if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(attn_decode_kernel, 160 * 1024, lds_raised));
   attn_decode_kernel<<<nh, 256, lds, s>>>(q, kc, vc, out, nh, nkv, hd, seq_len, pos_dev, scale);
   TL_HIP(hipGetLastError());
   return 0;
@@ -458,12 +454,8 @@ extern "C" int tl_attention_batch_prefill(const float* q_batch_dev, const float*
                                        num_q_heads, num_kv_heads, head_dim, scale, static_cast<hipStream_t>(stream));
   const size_t lds = sizeof(float) * (32 + 4 * (size_t)head_dim + (size_t)(start_pos + num_tokens));
   TL_REQUIRE(lds <= 160 * 1024, "tl_attention_batch_prefill: sequence too long for LDS scores (%zu B)", lds);
-  static bool attr = false;
-  if (!attr) {
-    TL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_prefill_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(attn_prefill_kernel, 160 * 1024, lds_raised));
   attn_prefill_kernel<<<num_tokens * num_q_heads, 256, lds, static_cast<hipStream_t>(stream)>>>(
       q_batch_dev, k_cache_dev, v_cache_dev, out_batch_dev, num_tokens, start_pos, num_q_heads, num_kv_heads,
       head_dim, scale);

@@ -219,6 +219,11 @@ int tl_peer_error_async(TlPeer* p, unsigned* flag_host, hipStream_t s) {
   return 0;
 }
 
+int tl_peer_clear_error(TlPeer* p, hipStream_t s) {
+  TL_HIP(hipMemsetAsync(p->err, 0, sizeof(unsigned), s));
+  return 0;
+}
+
 // Collective self-check (every rank of the group calls it once after tl_peer_connect): three all-reduces (both slots
 // and one reuse) and two all-gathers of rank-dependent patterns with known results. Returns 0 and *ok_out = 1 when
 // every value arrived exactly; *ok_out = 0 on a timeout or a wrong value (the caller then keeps the library collective).

@@ -32,7 +32,10 @@ def worker(rank, tp_size, hidden, iters, workdir, device=0, rv_timeout=120.0):
     if not tp.peer_link(m, rv.gather, rv.agree):
         print(f"rank {rank}: not linked: {E.lib().tl_last_error().decode(errors='replace')}")
         return 3
-    m.load(tensors)
+    for name, (typ, arr, rows, cols) in tensors.items():
+        m.set_tensor(name, typ, arr, rows, cols)
+    rv.agree(True)  # the warm-up step inside finalize is a collective of the group: enter it together
+    m.finalize()
     rv.agree(True)
     us, nbytes = m.bench_kernel("tp_all_reduce", iters=iters, warmup=200)
     ids = m.generate_greedy(1, 0, 32)

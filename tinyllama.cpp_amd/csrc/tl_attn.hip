@@ -25,9 +25,7 @@
 
 #include <type_traits>
 
-#include "tl_internal.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "tl_chunk.h"
 
 namespace {
 
@@ -45,18 +43,29 @@ __device__ __forceinline__ void rope2(float a, float b, float c, float s, float&
   o1 = __fadd_rn(__fmul_rn(a, s), __fmul_rn(b, c));
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane of the row (no LDS traffic)
+__device__ __forceinline__ float row_sum16(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ float dot4(f32x4 x, f32x4 y) { return (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]); }
+
 template <int HD, int G, bool FUSE>
 __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs a) {
-  constexpr int LP = HD / 4;             // lanes per K/V row
-  constexpr int PP = 64 / LP;            // rows per wave load
-  constexpr int U = 16;                  // K and V rows in flight per lane: 256 rows per batch and workgroup at HD 128
+  constexpr int LP = 16;                 // lanes per K/V row = one DPP row: the dot's reduction is four DPP adds
+  constexpr int NV = HD / 64;            // 16-byte loads per lane and row: lane ln holds d in [4 ln, 4 ln + 4) (+ 64)
+  constexpr int PP = 64 / LP;            // rows per wave load = row groups per wave
+  constexpr int NR = ATT_NW * PP;        // row groups per workgroup, each with its own running softmax state
+  constexpr int U = 16 / NV;             // row slots in flight per lane (128 VGPRs of K and V): 256 rows per workgroup at hd 128
+  constexpr int SB = 4;                  // slots folded at a time, in arrival order, while the later ones are in flight
   constexpr int RECL = HD + 4;           // partial record: out[HD], max, sum, 2 pad (16-B aligned)
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* qs = sm;                        // [G][HD]
-  float* kr = qs + G * HD;               // [HD] rotated k of the new position (FUSE owner)
-  float* vr = kr + HD;                   // [HD]
-  float* red = vr + HD;                  // 64 floats: M[g] at g, 1/L or L at 8 + g, flag at 32
-  float* part = red + 64;                // [ATT_NW][G][RECL]
+  float* red = sm;                       // 64 floats: M[g] at g, L at 8 + g
+  float* wts = red + 64;                 // [NR][G] weight of a row group's record in the split's partial
+  float* part = wts + NR * G;            // [NR][G][RECL]
   const int kvh = blockIdx.x, split = blockIdx.y;
   const int head0 = (kvh * gridDim.z + blockIdx.z) * G;  // gridDim.z workgroups share a kv head, G query heads each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -68,55 +77,66 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   const int kv_dim = a.nkv * HD;
   const int t0 = split * SL;
   const int t1 = len < t0 + SL ? len : t0 + SL;
-  const bool owner = FUSE && split == active - 1;  // this split holds the new position, still only in registers
+  const bool owner = FUSE && split == active - 1;  // this split holds the new position, which is not in the cache yet
   const int ncache = owner ? t1 - t0 - 1 : t1 - t0;  // positions of this split that come from the cache
-
-  // ---- phase 0: query heads (and the new k / v) into LDS ---------------------------------------------------
-  constexpr int half = HD / 2;
-  if (FUSE) {
-    const float* tp = a.table + 2 * (size_t)pos * half;
-    for (int i = tid; i < G * half; i += ATT_THREADS) {
-      const int g = i / half, p = i % half;
-      const float* qh = a.q + (size_t)(head0 + g) * HD;
-      rope2(qh[2 * p], qh[2 * p + 1], tp[2 * p], tp[2 * p + 1], qs[g * HD + 2 * p], qs[g * HD + 2 * p + 1]);
-    }
-    if (owner) {
-      for (int p = tid; p < half; p += ATT_THREADS) {
-        const float* kh = a.k + (size_t)kvh * HD;
-        float o0, o1;
-        rope2(kh[2 * p], kh[2 * p + 1], tp[2 * p], tp[2 * p + 1], o0, o1);
-        kr[2 * p] = o0;
-        kr[2 * p + 1] = o1;
-        if (blockIdx.z == 0) {  // one of the workgroups that share the kv head writes the cache
-          float* dst = a.kc + (size_t)pos * kv_dim + (size_t)kvh * HD;
-          dst[2 * p] = o0;
-          dst[2 * p + 1] = o1;
-        }
-      }
-      for (int d = tid; d < HD; d += ATT_THREADS) {
-        const float x = a.v[(size_t)kvh * HD + d];
-        vr[d] = x;
-        if (blockIdx.z == 0) a.vc[(size_t)pos * kv_dim + (size_t)kvh * HD + d] = x;
-      }
-    }
-  } else {
-    for (int i = tid; i < G * HD; i += ATT_THREADS) qs[i] = a.q[(size_t)head0 * HD + i];
-  }
-  __syncthreads();
-
-  // ---- phase 1: one pass over the rows with a running (max, sum, out) per lane group (online softmax) ----------
   const int sub = lane / LP, ln = lane % LP;
-  f32x4 qf[G], acc[G];
+
+  // ---- loads, in the order they are needed (vmcnt retires in issue order): the query heads (+ the RoPE row), then the
+  //      first batch of K/V rows. No LDS staging and no barrier in front of the rows: every lane rotates the 4 * NV
+  //      elements of each query head it needs itself (the row groups repeat that, from L1/L2). Staging the heads through
+  //      LDS instead (one pair per thread, rows in flight across the barrier) measured slower at every length.
+  f32x4 qf[G][NV], tq[NV];
+  if (FUSE) {
+    const float* tp = a.table + (size_t)pos * HD;  // [hd/2][2]: pair p at 2p; the pairs of d = 4 ln .. 4 ln + 3 at 4 ln
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tq[v] = *reinterpret_cast<const f32x4*>(tp + 64 * v + 4 * ln);
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) qf[g][v] = *reinterpret_cast<const f32x4*>(a.q + (size_t)(head0 + g) * HD + 64 * v + 4 * ln);
+
+  const float* kbase = a.kc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
+  const float* vbase = a.vc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
+  f32x4 kk[U * NV], vv[U * NV];
+  unsigned valid = 0;  // bit u: slot u of the batch in flight holds a row of this split
+  // slot u of a batch holds row base + (u * NW + wave) * PP + sub (rows go round the waves first, so short splits use
+  // few slots in every wave); unconditional (clamped) loads: all K and V rows of the batch in flight together
+  auto issue = [&](int base, auto uc_c) __attribute__((always_inline)) {
+    constexpr int UC = decltype(uc_c)::value;
+    valid = 0;
+#pragma unroll
+    for (int u = 0; u < UC; ++u) {
+      const int idx = base + (u * ATT_NW + wave) * PP + sub;
+      const bool ok = idx < ncache;
+      valid |= ok ? 1u << u : 0u;
+      const size_t off = (size_t)(ok ? idx : ncache - 1) * kv_dim;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        kk[u * NV + v] = *reinterpret_cast<const f32x4*>(kbase + off + 64 * v);
+        vv[u * NV + v] = *reinterpret_cast<const f32x4*>(vbase + off + 64 * v);
+      }
+    }
+  };
+  // slot class of a batch for this wave (wave-uniform): 0 (no rows), 2, 4, 8 or U
+  auto slot_class = [&](int base) __attribute__((always_inline)) {
+    const int mine = ncache - base - wave * PP;  // rows at or after this wave's first slot
+    if (mine <= 0) return 0;
+    const int slots = (mine + ATT_NW * PP - 1) / (ATT_NW * PP);
+    return slots <= 2 ? 2 : slots <= 4 ? 4 : (slots <= 8 || U == 8) ? 8 : U;
+  };
+  // ---- one pass over the rows with a running (max, sum, out) per 16-lane row group (online softmax) -------------
+  f32x4 acc[G][NV];
   float m[G], l[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    qf[g] = *reinterpret_cast<const f32x4*>(qs + g * HD + 4 * ln);
-    acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[g][v] = f32x4{0.f, 0.f, 0.f, 0.f};
     m[g] = -INFINITY;
     l[g] = 0.f;
   }
-  // rows [r0, r0 + cnt) of `kk`/`vv` hold valid[u]; folds them into the running state
-  auto fold = [&](const f32x4* kk, const f32x4* vv, const bool* valid, auto cnt_c) {
+  // folds `cnt` row slots (K rows kk_, V rows vv_, validity bits valid_) into the running state
+  auto fold = [&](const f32x4* kk_, const f32x4* vv_, unsigned valid_, auto cnt_c) __attribute__((always_inline)) {
     constexpr int cnt = decltype(cnt_c)::value;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -124,114 +144,147 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
       float mx = m[g];
 #pragma unroll
       for (int u = 0; u < cnt; ++u) {
-        float d = (qf[g][0] * kk[u][0] + qf[g][1] * kk[u][1]) + (qf[g][2] * kk[u][2] + qf[g][3] * kk[u][3]);
-#pragma unroll
-        for (int o = LP / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-        s[u] = valid[u] ? d * a.scale : -INFINITY;
+        float d = dot4(qf[g][0], kk_[u * NV]);
+        if (NV == 2) d += dot4(qf[g][NV - 1], kk_[u * NV + NV - 1]);
+        d = row_sum16(d);
+        s[u] = (valid_ >> u & 1u) ? d * a.scale : -INFINITY;
         mx = fmaxf(mx, s[u]);
       }
-      if (mx == -INFINITY) continue;  // nothing valid yet (uniform over the lane group)
+      if (mx == -INFINITY) continue;  // nothing valid yet (uniform over the row group)
       const float corr = safe_exp_diff(m[g], mx);
       m[g] = mx;
       l[g] *= corr;
-      acc[g][0] *= corr; acc[g][1] *= corr; acc[g][2] *= corr; acc[g][3] *= corr;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        acc[g][v][0] *= corr; acc[g][v][1] *= corr; acc[g][v][2] *= corr; acc[g][v][3] *= corr;
+      }
 #pragma unroll
       for (int u = 0; u < cnt; ++u) {
-        const float p = valid[u] ? expf(s[u] - mx) : 0.f;
+        const float p = (valid_ >> u & 1u) ? expf(s[u] - mx) : 0.f;
         l[g] += p;
-        acc[g][0] = fmaf(p, vv[u][0], acc[g][0]);
-        acc[g][1] = fmaf(p, vv[u][1], acc[g][1]);
-        acc[g][2] = fmaf(p, vv[u][2], acc[g][2]);
-        acc[g][3] = fmaf(p, vv[u][3], acc[g][3]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          acc[g][v][0] = fmaf(p, vv_[u * NV + v][0], acc[g][v][0]);
+          acc[g][v][1] = fmaf(p, vv_[u * NV + v][1], acc[g][v][1]);
+          acc[g][v][2] = fmaf(p, vv_[u * NV + v][2], acc[g][v][2]);
+          acc[g][v][3] = fmaf(p, vv_[u * NV + v][3], acc[g][v][3]);
+        }
       }
     }
   };
-  const float* kbase = a.kc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
-  const float* vbase = a.vc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
-  // one batch of UC row slots per lane group: slot u holds row base + (u * NW + wave) * PP + sub (rows go round the
-  // waves first, so short splits use few slots in every wave). UC is compile-time: 2, 4, 8 or U.
-  auto batch = [&](int base, auto uc_c) {
+  auto fold_batch = [&](auto uc_c) __attribute__((always_inline)) {
     constexpr int UC = decltype(uc_c)::value;
-    f32x4 kk[UC], vv[UC];
-    bool valid[UC];
+    constexpr int C = UC < SB ? UC : SB;
 #pragma unroll
-    for (int u = 0; u < UC; ++u) {  // unconditional (clamped) loads: all K and V rows of the batch in flight together
-      const int idx = base + (u * ATT_NW + wave) * PP + sub;
-      valid[u] = idx < ncache;
-      const size_t off = (size_t)(valid[u] ? idx : ncache - 1) * kv_dim;
-      kk[u] = *reinterpret_cast<const f32x4*>(kbase + off);
-      vv[u] = *reinterpret_cast<const f32x4*>(vbase + off);
-    }
-    fold(kk, vv, valid, uc_c);
+    for (int u0 = 0; u0 < UC; u0 += C) fold(kk + u0 * NV, vv + u0 * NV, valid >> u0, std::integral_constant<int, C>{});
   };
-  for (int base = 0; base < ncache; base += ATT_NW * PP * U) {
-    const int mine = ncache - base - wave * PP;  // rows at or after this wave's first slot (wave-uniform)
-    if (mine <= 0) continue;
-    const int slots = (mine + ATT_NW * PP - 1) / (ATT_NW * PP);
-    if (slots <= 2) batch(base, std::integral_constant<int, 2>{});
-    else if (slots <= 4) batch(base, std::integral_constant<int, 4>{});
-    else if (U > 8 && slots <= 8) batch(base, std::integral_constant<int, 8>{});
-    else batch(base, std::integral_constant<int, U>{});
+  // The first batch of NW * PP * U rows (the only one unless len > 8192 at hd 128): its loads are issued BEFORE the query
+  // rotation, which then waits for the q loads only; the row slots are folded in arrival order.
+  const int uc0 = slot_class(0);
+  if (uc0 == 2) issue(0, std::integral_constant<int, 2>{});
+  else if (uc0 == 4) issue(0, std::integral_constant<int, 4>{});
+  else if (uc0 == 8) issue(0, std::integral_constant<int, 8>{});
+  else if (uc0 == U) issue(0, std::integral_constant<int, U>{});
+  if (FUSE) {  // adjacent-pair rotation of the query elements in registers
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        f32x4 r;
+        float o0, o1;
+        rope2(qf[g][v][0], qf[g][v][1], tq[v][0], tq[v][1], o0, o1);
+        r[0] = o0; r[1] = o1;
+        rope2(qf[g][v][2], qf[g][v][3], tq[v][2], tq[v][3], o0, o1);
+        r[2] = o0; r[3] = o1;
+        qf[g][v] = r;
+      }
   }
-  if (owner && wave == ATT_NW - 1) {  // the new position, from LDS (the last wave has the fewest cache rows)
-    f32x4 kk[1], vv[1];
-    bool valid[1];
-    kk[0] = *reinterpret_cast<const f32x4*>(kr + 4 * ln);
-    vv[0] = *reinterpret_cast<const f32x4*>(vr + 4 * ln);
-    valid[0] = sub == 0;
-    fold(kk, vv, valid, std::integral_constant<int, 1>{});
+  if (uc0 == 2) fold_batch(std::integral_constant<int, 2>{});
+  else if (uc0 == 4) fold_batch(std::integral_constant<int, 4>{});
+  else if (uc0 == 8) fold_batch(std::integral_constant<int, 8>{});
+  else if (uc0 == U) fold_batch(std::integral_constant<int, U>{});
+  for (int base = ATT_NW * PP * U; base < ncache; base += ATT_NW * PP * U) {  // further batches: always the full slot class
+    if (slot_class(base) == 0) continue;
+    issue(base, std::integral_constant<int, U>{});
+    fold_batch(std::integral_constant<int, U>{});
   }
-  // fold the PP lane groups of a wave (shuffles), then the waves (LDS)
+  if (owner && wave == ATT_NW - 1) {
+    // the new position (the last wave has the fewest cache rows): rotate k, take v, write both into the cache (one of the
+    // workgroups that share the kv head does) and fold them from registers
+    f32x4 kn[NV], vn[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tq[v] = *reinterpret_cast<const f32x4*>(a.table + (size_t)pos * HD + 64 * v + 4 * ln);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const f32x4 kr = *reinterpret_cast<const f32x4*>(a.k + (size_t)kvh * HD + 64 * v + 4 * ln);
+      vn[v] = *reinterpret_cast<const f32x4*>(a.v + (size_t)kvh * HD + 64 * v + 4 * ln);
+      float o0, o1;
+      rope2(kr[0], kr[1], tq[v][0], tq[v][1], o0, o1);
+      kn[v][0] = o0; kn[v][1] = o1;
+      rope2(kr[2], kr[3], tq[v][2], tq[v][3], o0, o1);
+      kn[v][2] = o0; kn[v][3] = o1;
+      if (sub == 0 && blockIdx.z == 0) {
+        *reinterpret_cast<f32x4*>(a.kc + (size_t)pos * kv_dim + (size_t)kvh * HD + 64 * v + 4 * ln) = kn[v];
+        *reinterpret_cast<f32x4*>(a.vc + (size_t)pos * kv_dim + (size_t)kvh * HD + 64 * v + 4 * ln) = vn[v];
+      }
+    }
+    fold(kn, vn, sub == 0 ? 1u : 0u, std::integral_constant<int, 1>{});
+  }
+
+  // ---- the NR row groups' states -> LDS records; weights exp(m_r - M) per (row group, head); the split's partial ------
+  // (merging the row groups of a wave in registers first costs 2 x 10 cross-row exchanges per head and lane: more than
+  //  the whole fold of a short split)
+  const int rg = wave * PP + sub;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
+    float* rec = part + (size_t)(rg * G + g) * RECL;
 #pragma unroll
-    for (int o = 32; o >= LP; o >>= 1) {
-      const float mo = __shfl_xor(m[g], o);
-      const float mn = fmaxf(m[g], mo);
-      const float c = safe_exp_diff(m[g], mn), co = safe_exp_diff(mo, mn);
-      l[g] = l[g] * c + __shfl_xor(l[g], o) * co;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[g][e] = acc[g][e] * c + __shfl_xor(acc[g][e], o) * co;
-      m[g] = mn;
-    }
-    if (sub == 0) {
-      float* rec = part + (size_t)(wave * G + g) * RECL;
-      *reinterpret_cast<f32x4*>(rec + 4 * ln) = acc[g];
-      if (ln == 0) {
-        rec[HD] = m[g];
-        rec[HD + 1] = l[g];
-      }
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(rec + 64 * v + 4 * ln) = acc[g][v];
+    if (ln == 0) {
+      rec[HD] = m[g];
+      rec[HD + 1] = l[g];
     }
   }
   __syncthreads();
-  if (tid < G) {  // split-wide max and sum per head
-    float M = -INFINITY;
-    for (int w = 0; w < ATT_NW; ++w) M = fmaxf(M, part[(size_t)(w * G + tid) * RECL + HD]);
-    float L = 0.f;
-    for (int w = 0; w < ATT_NW; ++w) {
-      const float* rec = part + (size_t)(w * G + tid) * RECL;
-      L += rec[HD + 1] * safe_exp_diff(rec[HD], M);
+  if (tid < NR * G) {  // NR = 32 consecutive lanes per head: split-wide max, weights and sum
+    const int g = tid / NR, r = tid % NR;
+    const float* rec = part + (size_t)(r * G + g) * RECL;
+    const float mr = rec[HD];
+    float M = mr;
+#pragma unroll
+    for (int o = NR / 2; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+    const float w = safe_exp_diff(mr, M);
+    wts[r * G + g] = w;
+    float L = rec[HD + 1] * w;
+#pragma unroll
+    for (int o = NR / 2; o >= 1; o >>= 1) L += __shfl_xor(L, o);
+    if (r == 0) {
+      red[g] = M;
+      red[8 + g] = L;
     }
-    red[tid] = M;
-    red[8 + tid] = L;
   }
   __syncthreads();
-
-  // ---- phase 2: the split's partial per head: ws[head][split] = {out[HD] (unnormalised), max, sum} -----------------
+  // ws[head][split] = {out[HD] (unnormalised), max, sum}: four lanes share an output quad, each sums a quarter of the
+  // row groups (in a fixed order), then the quad is summed with two DPP steps
   for (int i = tid; i < G * HD; i += ATT_THREADS) {
-    const int g = i / HD, d = i % HD;
-    const float M = red[g];
-    float o = 0.f;
+    const int rq = i & 3, d4 = (i >> 2) % (HD / 4), g = i / HD;
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < ATT_NW; ++w) {
-      const float* rec = part + (size_t)(w * G + g) * RECL;
-      o += rec[d] * safe_exp_diff(rec[HD], M);
+    for (int j = 0; j < NR / 4; ++j) {
+      const int r = rq * (NR / 4) + j;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(part + (size_t)(r * G + g) * RECL + 4 * d4);
+      const float w = wts[r * G + g];
+      o[0] = fmaf(x[0], w, o[0]); o[1] = fmaf(x[1], w, o[1]); o[2] = fmaf(x[2], w, o[2]); o[3] = fmaf(x[3], w, o[3]);
     }
-    float* rec = a.ws + ((size_t)(head0 + g) * TL_ATTN_MAX_SPLITS + split) * RECL;
-    rec[d] = o;
-    if (d == 0) {
-      rec[HD] = M;
-      rec[HD + 1] = red[8 + g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = dpp_add<0x4E, 0xf>(dpp_add<0xB1, 0xf>(o[e]));
+    if (rq == 0) {
+      float* rec = a.ws + ((size_t)(head0 + g) * TL_ATTN_MAX_SPLITS + split) * RECL;
+      *reinterpret_cast<f32x4*>(rec + 4 * d4) = o;
+      if (d4 == 0) {
+        rec[HD] = red[g];
+        rec[HD + 1] = red[8 + g];
+      }
     }
   }
 }
@@ -280,7 +333,7 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
 
 template <int HD, int G>
 int launch_hg(const AttnArgs& a, bool fuse, hipStream_t s) {
-  const size_t lds = sizeof(float) * ((size_t)G * HD + 2 * HD + 64 + (size_t)ATT_NW * G * (HD + 4));
+  const size_t lds = sizeof(float) * (64 + (size_t)ATT_NW * 4 * G + (size_t)ATT_NW * 4 * G * (HD + 4));
   const dim3 grid(a.nkv, TL_ATTN_MAX_SPLITS, (a.nh / a.nkv) / G);
   if (fuse) {
     static TlDeviceOnce lds_raised;  // per kernel instantiation, per device

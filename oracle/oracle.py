@@ -290,6 +290,13 @@ class OracleModel:
         p = self.o.L.tlo_model_kcache(self.h, layer)
         return np.ctypeslib.as_array(p, shape=(n_pos, kvd)).copy()
 
+    def set_kv(self, layer, k, v):
+        """Overwrite the first len(k) positions of a layer's K/V cache (long-context tests seed both sides this way
+        instead of paying thousands of CPU forward passes)."""
+        kvd = self.cfg["n_kv_heads"] * (self.cfg["hidden"] // self.cfg["n_heads"])
+        for p, a in ((self.o.L.tlo_model_kcache(self.h, layer), k), (self.o.L.tlo_model_vcache(self.h, layer), v)):
+            np.ctypeslib.as_array(p, shape=(a.shape[0], kvd))[...] = a
+
     def vcache(self, layer, n_pos):
         kvd = self.cfg["n_kv_heads"] * (self.cfg["hidden"] // self.cfg["n_heads"])
         p = self.o.L.tlo_model_vcache(self.h, layer)

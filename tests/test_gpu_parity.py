@@ -348,6 +348,37 @@ def test_model_llama32_3b_shape_two_layers(E, pkg, oracle, mix):
     om.close()
 
 
+@pytest.mark.parametrize("start", [300, 1500, 8000])
+def test_model_8b_shape_long_context_decode(E, pkg, oracle, start):
+    """Llama-3-8B's layer shape (H 4096, 32/8 heads of 128, I 14336) at 2 layers and a cut vocabulary, decoding at
+    positions start.. over K/V caches seeded with the same random rows on both sides: the split attention with many
+    splits (its in-kernel merge from 9 splits on; 32 splits of 256 rows at 8000) inside the captured step, vs the oracle."""
+    cfg = dict(pkg.synth.SHAPES["llama-3-8b"], n_layers=2, vocab=2048, max_pos=8192)
+    cfg, tensors = pkg.synth.build_model(cfg, "q4_k_m", seed=17)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    kvd = cfg["n_kv_heads"] * (cfg["hidden"] // cfg["n_heads"])
+    rng = np.random.default_rng(start)
+    for layer in range(cfg["n_layers"]):
+        k = (rng.standard_normal((start, kvd)) * 0.7).astype(np.float32)
+        v = rng.standard_normal((start, kvd)).astype(np.float32)
+        m.set_kv_cache(layer, k, v)
+        om.set_kv(layer, k, v)
+    tok = 5
+    for pos in range(start, start + 3):
+        got, nxt = m.decode(tok, pos)
+        _, want = om.forward(om.lookup_embedding(tok), pos)
+        assert close(got, want, LOGIT_TOL).all(), (pos, np.abs(got - want).max())
+        assert nxt == int(np.argmax(want))
+        tok = nxt
+    for layer in range(cfg["n_layers"]):  # the new positions' K/V rows were written by the fused kernel
+        k, v = m.kv_cache(layer, start + 3)
+        assert close(k[start:], om.kcache(layer, start + 3)[start:], LOGIT_TOL).all()
+        assert close(v[start:], om.vcache(layer, start + 3)[start:], LOGIT_TOL).all()
+    m.free()
+    om.close()
+
+
 def test_token_outside_the_vocabulary_embeds_as_zeros(E, pkg, oracle):
     """lookup_embedding returns a zero vector for an id outside the table (model_utils.cpp:15-19) and the forward pass
     carries on from it: the decode route (graph step) and the batched prefill route must do the same."""

@@ -9,18 +9,27 @@
 // Shape (HBM/latency-bound byte work, no MFMA):
 //   - grid (kv head, sequence split, head-group part): one workgroup serves the query heads of a kv head (GQA group), so
 //     every K/V byte is read once; groups of 8 heads (TinyLlama, the 70B shape) are served by two workgroups of 4 (their
-//     K/V rows are read twice, the per-row softmax work per workgroup halves: +11 % tokens/s on TinyLlama-1.1B); a split is max(32, pow2(len / 32)) positions (tl_attn_split_len): at most 32 splits, so that
-//     8 kv heads fill 256 CUs from 1024 positions on while short contexts still spread over tens of CUs (one CU only
-//     pulls ~25-50 GB/s);
-//   - a K/V row is read by HD/4 lanes x 16 B (two or four rows per wave load); the K AND V rows of a batch (up to 16 of
-//     each per lane) are in flight together and folded into a running (max, sum, out) per lane group (online softmax),
-//     so a split of 256 positions costs one memory round trip;
-//   - every split writes a (max, sum, unnormalised out) partial per head; the partials are combined at the next kernel
-//     boundary: in the x-staging prologue of the attn_output GEMV (tl_gemv.hip), or by attn_combine_kernel for the
-//     operator-level API. (An in-launch combine by the last-arriving workgroup costs a release fence, an atomic and an
-//     acquire fence, ~4 us, more than the attention itself at short context.)
-//   - FUSE: the workgroup rotates its query heads into LDS; the split that owns the new position rotates k, writes
-//     K/V of that position into the cache and takes that position's score/value from LDS instead of from memory.
+//     K/V rows are read twice, the per-row softmax work per workgroup halves: +11 % tokens/s on TinyLlama-1.1B); a split
+//     is max(64, pow2(len / 32)) positions (tl_attn_split_len): at most 32 splits, so that 8 kv heads fill 256 CUs from
+//     2048 positions on while short contexts still spread over tens of CUs;
+//   - a K/V row is read by 16 lanes (one DPP row) x 16 B x hd/64 loads, four rows per wave load; the dot's reduction is
+//     four DPP adds (quad_perm, row_half_mirror, row_mirror) and every lane of the row ends up with the score. (The first
+//     version used 32 lanes per row and __shfl_xor, which is ds_bpermute here: 640 LDS-path shuffles per workgroup pass.)
+//     All K AND V rows of a batch (128 VGPRs per lane, 256 rows per workgroup at hd 128) are in flight together and are
+//     folded four slots at a time in arrival order into a running (max, sum, out) per row group (online softmax), so the
+//     fold of the early rows overlaps the arrival of the late ones;
+//   - the 32 row groups of a workgroup leave their states in LDS records; 32 lanes per head compute the weights
+//     exp(m_r - M), and the records are summed by quads of lanes (a register merge of the 4 row groups of a wave costs
+//     2 x 10 cross-row exchanges per head: +1.4 us at short context);
+//   - every split writes a (max, sum, unnormalised out) partial per head. Up to 16 splits the partials are combined at
+//     the next kernel boundary: in the x-staging prologue of the attn_output GEMV (tl_gemv.hip), or by
+//     attn_combine_kernel for the operator-level API. From 17 splits on (AttnArgs::done_cnt set) the last workgroup of a
+//     head group to finish merges the group's partials into record 0 (written-through stores, one counter add per
+//     workgroup, agent-scope loads): +3.9 us on this kernel, but the GEMV, whose 256 workgroups each re-read every
+//     record, drops from 18.6 to 10.2 us at 32 splits;
+//   - FUSE: every lane rotates the query elements it needs in registers (no LDS staging, no barrier in front of the
+//     rows); the split that owns the new position rotates k, writes K/V of that position into the cache and folds that
+//     position from registers instead of from memory.
 #include <math.h>
 
 #include <type_traits>
@@ -50,6 +59,14 @@ __device__ __forceinline__ float row_sum16(float v) {
   v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
   v = dpp_add<0x140, 0xf>(v);  // row_mirror
   return v;
+}
+// agent-scope accesses for data handed between workgroups inside one launch (the L2s of the 8 XCDs are not coherent with
+// each other for ordinary accesses)
+__device__ __forceinline__ void st_agent(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float dot4(f32x4 x, f32x4 y) { return (x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3]); }
 
@@ -264,6 +281,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
     }
   }
   __syncthreads();
+  const bool merge = a.done_cnt != nullptr && active >= TL_ATTN_MERGE_MIN;
   // ws[head][split] = {out[HD] (unnormalised), max, sum}: four lanes share an output quad, each sums a quarter of the
   // row groups (in a fixed order), then the quad is summed with two DPP steps
   for (int i = tid; i < G * HD; i += ATT_THREADS) {
@@ -280,11 +298,78 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
     for (int e = 0; e < 4; ++e) o[e] = dpp_add<0x4E, 0xf>(dpp_add<0xB1, 0xf>(o[e]));
     if (rq == 0) {
       float* rec = a.ws + ((size_t)(head0 + g) * TL_ATTN_MAX_SPLITS + split) * RECL;
-      *reinterpret_cast<f32x4*>(rec + 4 * d4) = o;
-      if (d4 == 0) {
-        rec[HD] = red[g];
-        rec[HD + 1] = red[8 + g];
+      if (merge) {
+        // agent-scope stores (written through): the merging workgroup may sit on another XCD, behind another L2
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st_agent(rec + 4 * d4 + e, o[e]);
+        if (d4 == 0) {
+          st_agent(rec + HD, red[g]);
+          st_agent(rec + HD + 1, red[8 + g]);
+        }
+      } else {
+        *reinterpret_cast<f32x4*>(rec + 4 * d4) = o;
+        if (d4 == 0) {
+          rec[HD] = red[g];
+          rec[HD + 1] = red[8 + g];
+        }
       }
+    }
+  }
+  if (!merge) return;  // the consumer combines the records itself
+
+  // ---- many splits: the LAST workgroup of this head group to get here merges the group's records into record 0, so
+  //      that the consumer (every workgroup of the attn_output GEMV re-reads the partials) finds one record per head.
+  //      Hand-off: written-through record stores, vmcnt(0), barrier, one relaxed agent-scope counter add per workgroup;
+  //      the last one reads the records with agent-scope loads. The counter is left at zero for the next launch.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's record stores have been acknowledged
+  __syncthreads();
+  if (tid == 0) {
+    unsigned* c = a.done_cnt + kvh * gridDim.z + blockIdx.z;
+    const unsigned before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = before + 1u == (unsigned)active;
+    if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    red[32] = last ? 1.f : 0.f;
+  }
+  __syncthreads();
+  if (red[32] == 0.f) return;
+  static_assert(G * HD <= ATT_THREADS && G * TL_ATTN_MAX_SPLITS <= ATT_THREADS, "one element per thread in the merge");
+  const bool mine = tid < G * HD;
+  const int g = mine ? tid / HD : 0, d = tid % HD;
+  float* rec0 = a.ws + (size_t)(head0 + g) * TL_ATTN_MAX_SPLITS * RECL;
+  float o[TL_ATTN_MAX_SPLITS];
+  if (mine) {
+#pragma unroll
+    for (int sp = 0; sp < TL_ATTN_MAX_SPLITS; ++sp)  // all records in flight together (clamped, unconditional)
+      o[sp] = ld_agent(rec0 + (size_t)(sp < active ? sp : active - 1) * RECL + d);
+  }
+  // meanwhile: (max, sum) of every record once, by 32 consecutive lanes per head -> weights in LDS (wts is free again)
+  if (tid < G * TL_ATTN_MAX_SPLITS) {
+    const int gg = tid / TL_ATTN_MAX_SPLITS, sp = tid % TL_ATTN_MAX_SPLITS;
+    const float* rec = a.ws + ((size_t)(head0 + gg) * TL_ATTN_MAX_SPLITS + (sp < active ? sp : active - 1)) * RECL;
+    const float ms = sp < active ? ld_agent(rec + HD) : -INFINITY;
+    const float ls = ld_agent(rec + HD + 1);
+    float M = ms;
+#pragma unroll
+    for (int x = TL_ATTN_MAX_SPLITS / 2; x >= 1; x >>= 1) M = fmaxf(M, __shfl_xor(M, x));
+    const float w = sp < active ? expf(ms - M) : 0.f;
+    wts[tid] = w;
+    float L = ls * w;
+#pragma unroll
+    for (int x = TL_ATTN_MAX_SPLITS / 2; x >= 1; x >>= 1) L += __shfl_xor(L, x);
+    if (sp == 0) {
+      red[gg] = M;
+      red[8 + gg] = L;
+    }
+  }
+  __syncthreads();  // weights ready; record 0 has been read (into registers) by everyone before it is overwritten
+  if (mine) {
+    float O = 0.f;
+#pragma unroll
+    for (int sp = 0; sp < TL_ATTN_MAX_SPLITS; ++sp) O = fmaf(o[sp], wts[g * TL_ATTN_MAX_SPLITS + sp], O);  // split order
+    rec0[d] = O;
+    if (d == 0) {
+      rec0[HD] = red[g];
+      rec0[HD + 1] = red[8 + g];
     }
   }
 }

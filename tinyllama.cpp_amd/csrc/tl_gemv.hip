@@ -42,6 +42,7 @@ struct GemvVec {
   const float* attn_ws;
   const int* attn_pos;
   int attn_hd;
+  int attn_merged;
 };
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
@@ -97,9 +98,7 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
   if (XATTN) {
     int pos;  // scalar load: its own counter, so the partial loads below need not wait behind anything
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.attn_pos) : "memory");
-    const int len = pos + 1;
-    const int sl = tl_attn_split_len(len);
-    r.active = (len + sl - 1) / sl;
+    r.active = tl_attn_records(pos + 1, a.attn_merged != 0);
     const int i = threadIdx.x < (unsigned)n4 ? threadIdx.x : n4 - 1;
     xattn_issue(a, i, 0, r.active, r.ao, r.am, r.al);
     return;
@@ -727,7 +726,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
-  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd};
+  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged};
   for (int i = 0; i < 3; ++i) L.seg[i] = a.seg[i < a.nseg ? i : 0];
   const int ta = a.seg[0].w.type;
   bool flat_ok = true;

@@ -131,6 +131,7 @@ struct GemvArgs {
   const float* attn_ws;
   const int* attn_pos;  // device position (sequence length - 1)
   int attn_hd;
+  int attn_merged;      // 1: the split kernel ran with AttnArgs::done_cnt (one record per head from TL_ATTN_MERGE_MIN splits on)
   int role;             // GemvRole: selects a separately named instantiation (profiling only)
 };
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
@@ -147,11 +148,24 @@ int tl_launch_attn_decode(const float* q, const float* kc, const float* vc, floa
                           int seq_len, const int* pos_dev, int max_seq, float scale, hipStream_t s);
 // split decode attention (tl_attn.hip)
 constexpr int TL_ATTN_MAX_SPLITS = 32;
-// positions per split for a sequence of `len` positions: max(32, pow2ceil(len / 32)) -> at most 32 splits
+// positions per split for a sequence of `len` positions: max(64, pow2ceil(len / 32)) -> at most 32 splits. 64 rows are
+// two row slots per wave of the split kernel, the smallest unit it issues anyway; 32-row splits only doubled the records
+// the consumer has to combine (len 500: attention + attn_output 22.8 -> 20.3 us per layer).
 __host__ __device__ inline int tl_attn_split_len(int len) {
-  int sl = 32;
+  int sl = 64;
   while (sl * TL_ATTN_MAX_SPLITS < len) sl <<= 1;
   return sl;
+}
+// Number of splits from which the split kernel merges its own partials (the last workgroup of a head group to finish
+// does it, when AttnArgs::done_cnt is set) instead of leaving `active` records per head to the consumer: the attn_output
+// GEMV re-reads every record in all 256 workgroups: measured 9.7 us at 5 splits, 18.6 us at 32 (+0.33 us per split)
+// against +3.9 us for the in-kernel merge, which therefore pays from 17 splits on.
+constexpr int TL_ATTN_MERGE_MIN = 17;
+// records per head the consumer of the partials has to combine for a sequence of `len` positions
+__host__ __device__ inline int tl_attn_records(int len, bool merged) {
+  const int sl = tl_attn_split_len(len);
+  const int active = (len + sl - 1) / sl;
+  return merged && active >= TL_ATTN_MERGE_MIN ? 1 : active;
 }
 struct AttnArgs {
   const float* q;        // [nh][hd]; FUSE: un-rotated (rotated into LDS only)
@@ -167,6 +181,9 @@ struct AttnArgs {
   const int* pos_dev;    // != NULL: the new position lives on the device (graph replay); seq_len = *pos_dev + 1
   int max_seq;
   float scale;
+  // != NULL: one zero-initialised counter per head group (nh / G of them; the kernel leaves them at zero). From
+  // TL_ATTN_MERGE_MIN active splits on, the last workgroup of a head group merges the group's partials into record 0
+  unsigned* done_cnt;
 };
 bool tl_attn_split_supported(int nh, int nkv, int hd);
 size_t tl_attn_ws_floats(int nh, int hd);

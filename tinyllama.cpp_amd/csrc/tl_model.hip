@@ -429,6 +429,7 @@ static GemvArgs args_attn_out(tl_model* m, int l) {
     o.attn_ws = m->attn_ws;
     o.attn_pos = m->state + 1;
     o.attn_hd = m->head_dim;
+    o.attn_merged = 1;
   }
   o.resid = m->rank == 0 ? m->x : m->zeros;
   o.role = GEMV_ATTN_OUT;
@@ -542,6 +543,7 @@ static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) 
     t.pos_dev = pos_dev;
     t.max_seq = c.max_position_embeddings;
     t.scale = scale;
+    t.done_cnt = reinterpret_cast<unsigned*>(m->attn_ws + tl_attn_ws_floats(m->nh_l, m->head_dim));  // nh_l counters
     PROF_MARK(2);
     TL_TRY(tl_launch_attn_split(t, true, s));
   } else {
@@ -791,7 +793,11 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->cand_v, sizeof(float) * ARGMAX_SLICES));
   TL_HIP(hipMalloc(&m->cand_i, sizeof(int) * ARGMAX_SLICES));
   m->attn_split = tl_attn_split_supported(m->nh_l, m->nkv_l, m->head_dim);
-  if (m->attn_split) TL_HIP(hipMalloc(&m->attn_ws, sizeof(float) * tl_attn_ws_floats(m->nh_l, m->head_dim)));
+  if (m->attn_split) {  // partial records + one arrival counter per head group (zero between launches)
+    const size_t ws_bytes = sizeof(float) * (tl_attn_ws_floats(m->nh_l, m->head_dim) + (size_t)m->nh_l);
+    TL_HIP(hipMalloc(&m->attn_ws, ws_bytes));
+    TL_HIP(hipMemsetAsync(m->attn_ws, 0, ws_bytes, m->stream));
+  }
   m->hist_cap = (int)P + 64;
   TL_HIP(hipMalloc(&m->state, sizeof(int) * (kStateHeaderInts + m->hist_cap)));
   TL_HIP(hipMemsetAsync(m->state, 0, sizeof(int) * (kStateHeaderInts + m->hist_cap), m->stream));

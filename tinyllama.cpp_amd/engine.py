@@ -385,6 +385,13 @@ class Model:
             out.append(a)
         return out
 
+    def set_kv_cache(self, layer, k, v):
+        """Overwrite the first len(k) positions of a layer's K/V cache from host arrays [n_pos][kv_dim] (tests)."""
+        for which, a in ((0, k), (1, v)):
+            a = np.ascontiguousarray(a, np.float32)
+            check(lib().tl_memcpy_h2d(self.device_ptr(which, layer), a.ctypes.data, a.nbytes, None), "h2d")
+        check(lib().tl_device_sync(), "sync")
+
     def bytes_per_token(self, pos):
         w, kv = C.c_double(), C.c_double()
         check(lib().tl_model_bytes_per_token(self.h, int(pos), C.byref(w), C.byref(kv)), "tl_model_bytes_per_token")

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   float* wts = red + 64;                 // [NR][G] weight of a row group's record in the split's partial
   float* part = wts + NR * G;            // [NR][G][RECL]
   const int kvh = blockIdx.x, split = blockIdx.y;
-  const int head0 = (kvh * gridDim.z + blockIdx.z) * G;  // gridDim.z workgroups share a kv head, G query heads each
+  const int head0 = (kvh * a.zparts + blockIdx.z) * G;  // a.zparts workgroups share a kv head, G query heads each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pos = a.pos_dev ? *a.pos_dev : a.seq_len - 1;
   const int len = pos + 1;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's record stores have been acknowledged
   __syncthreads();
   if (tid == 0) {
-    unsigned* c = a.done_cnt + kvh * gridDim.z + blockIdx.z;
+    unsigned* c = a.done_cnt + kvh * a.zparts + blockIdx.z;
     const unsigned before = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const bool last = before + 1u == (unsigned)active;
     if (last) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -417,7 +417,9 @@ __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restri
 }
 
 template <int HD, int G>
-int launch_hg(const AttnArgs& a, bool fuse, hipStream_t s) {
+int launch_hg(const AttnArgs& a_in, bool fuse, hipStream_t s) {
+  AttnArgs a = a_in;
+  a.zparts = (a.nh / a.nkv) / G;
   const size_t lds = sizeof(float) * (64 + (size_t)ATT_NW * 4 * G + (size_t)ATT_NW * 4 * G * (HD + 4));
   const dim3 grid(a.nkv, TL_ATTN_MAX_SPLITS, (a.nh / a.nkv) / G);
   if (fuse) {

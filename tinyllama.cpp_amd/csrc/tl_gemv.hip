@@ -43,6 +43,10 @@ struct GemvVec {
   const int* attn_pos;
   int attn_hd;
   int attn_merged;
+  // the launch geometry as EXPLICIT arguments: blockDim / gridDim live in the hidden argument block, which hipcc reads
+  // with separate scalar loads where first used: two more dependent round trips (~0.25 us each, cold scalar cache)
+  // between kernel entry and a wave's first weight load
+  int nthr, grid;
 };
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
@@ -107,12 +111,12 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
   const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
+    const int i = threadIdx.x + k * a.nthr;
     r.v[k] = x4[i < n4 ? i : n4 - 1];
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    const int i = threadIdx.x + k * blockDim.x;
+    const int i = threadIdx.x + k * a.nthr;
     r.g[k] = w4[i < n4 ? i : n4 - 1];
   }
 }
@@ -120,7 +124,7 @@ __device__ __forceinline__ float ssq4(f32x4 t) { return (t[0] * t[0] + t[1] * t[
 template <bool XATTN>
 __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r, float* smem) {
   float* xs = smem + XS_SCRATCH;
-  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tid = threadIdx.x, nthr = a.nthr;
   const int n4 = a.cols >> 2;
   if (XATTN) {
     // x = combined attention output: out = sum_s o_s e^(m_s - M) / (sum_s l_s e^(m_s - M) + 1e-9), utils.cpp:692
@@ -162,8 +166,8 @@ __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r,
 #pragma unroll
     for (int k = 0; k < 4; ++k) ssq += (tid + k * nthr < n4) ? ssq4(r.v[k]) : 0.f;
     for (int i = tid + 4 * nthr; i < n4; i += nthr) ssq += ssq4(x4[i]);
-    ssq = wave_sum_all(ssq);
-    if ((tid & 63) == 0) smem[tid >> 6] = ssq;
+    ssq = wave_sum_lane63(ssq);  // DPP only (the xor butterfly is six dependent LDS-path shuffles here)
+    if ((tid & 63) == 63) smem[tid >> 6] = ssq;
     __syncthreads();
     float tot = 0.f;
     for (int w = 0; w < (nthr >> 6); ++w) tot += smem[w];
@@ -330,6 +334,10 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   Step<TYPE> cur, nxt;
   StepMeta mc, mn;
   issue(cur, mc);  // the first step's loads go out before x is staged: the HBM round trip overlaps the prologue
+  // (Issuing a SECOND step ahead of the staging was tried twice and measured slower both times: in this loop the copy
+  //  form then waits for its own fresh loads, -10 %; as a loop-free variant for the launches with two steps per wave,
+  //  attn_output and QKV, -1.7 %: the x loads of the waves that start late queue behind twice as many weight loads of
+  //  the early ones, and staging ends with a barrier.)
   if (STAMP) ts[3] = __builtin_readcyclecounter();
   stage_x_finish<XATTN>(a, xr, smem);
   if (STAMP) ts[4] = __builtin_readcyclecounter();
@@ -530,7 +538,7 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
   // in four dependent round trips to a cold scalar cache (~2000 cycles before a wave's first weight load goes out).
   asm volatile("" ::"s"(sg0.w.p0), "s"(sg0.w.p1), "s"(sg0.w.p2), "s"(sg0.w.p3), "s"(sg0.w.rows), "s"(sg0.out),
                "s"(a.x), "s"(a.norm_w), "s"(a.resid), "s"(a.eps), "s"(a.cols), "s"(t0), "s"(t1), "s"(t2),
-               "s"(nsegA), "s"(wavesA));
+               "s"(nsegA), "s"(wavesA), "s"(a.nthr), "s"(a.grid));
   if (ROLE == GEMV_ATTN_OUT_COMBINE) asm volatile("" ::"s"(a.attn_ws), "s"(a.attn_pos), "s"(a.attn_hd));
   if (PAIR || ROLE == GEMV_QKV)
     asm volatile("" ::"s"(sg1.w.p0), "s"(sg1.w.p1), "s"(sg1.w.p2), "s"(sg1.w.p3), "s"(sg1.w.rows), "s"(sg1.out));
@@ -542,7 +550,7 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nwaves = blockDim.x >> 6;
+  const int nwaves = a.nthr >> 6;
   XRegs xr;
   stage_x_issue<XATTN>(a, xr);
   if (STAMP) ts[2] = __builtin_readcyclecounter();
@@ -551,24 +559,24 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
     const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
     const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, t0, nsegA >= 2 ? t1 : 0x3fffffff};
     if constexpr (RA > 0)
-      run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane);
+      run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane);
     else
-      run_class<TA, PAIR, RESID, XATTN, STAMP>(g, a, xr, smem, wave * gridDim.x + blockIdx.x, gridDim.x * wA, total, lane, ts);
+      run_class<TA, PAIR, RESID, XATTN, STAMP>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane, ts);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
     const int tb = nsegA == 1 ? t1 : t2;
     const Segs g = {sb.w, sb.w, sb.w, sb.out, sb.out, sb.out, 0x3fffffff, 0x3fffffff};
     if constexpr (RA > 0)
-      run_class_flat<TBB, false, false, XATTN, RA>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
-                                                   gridDim.x * (nwaves - wavesA), tb, lane);
+      run_class_flat<TBB, false, false, XATTN, RA>(g, a, xr, smem, (wave - wavesA) * a.grid + blockIdx.x,
+                                                   a.grid * (nwaves - wavesA), tb, lane);
     else
-      run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * gridDim.x + blockIdx.x,
-                                                 gridDim.x * (nwaves - wavesA), tb, lane, ts);
+      run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * a.grid + blockIdx.x,
+                                                 a.grid * (nwaves - wavesA), tb, lane, ts);
   }
   if (STAMP && lane == 0 && ts[5] != 0) {
     ts[7] = __builtin_readcyclecounter();
-    unsigned long long* o = a.stamps + 10 * (size_t)(wave * gridDim.x + blockIdx.x);
+    unsigned long long* o = a.stamps + 10 * (size_t)(wave * a.grid + blockIdx.x);
     for (int i = 0; i < 8; ++i) o[i] = ts[i];
     o[8] = __builtin_amdgcn_s_memrealtime();
     o[9] = rt0;
@@ -618,7 +626,10 @@ template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0>
 static int gemv_launch_ra(const Launch& L, hipStream_t s) {
   static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
   TL_TRY(tl_raise_lds_limit(gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA>, 160 * 1024, lds_raised));
-  gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], L.v, L.t[0],
+  GemvVec v = L.v;
+  v.nthr = L.threads;
+  v.grid = L.grid;
+  gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], v, L.t[0],
                                                                                L.t[1], L.t[2], L.nsegA, L.wavesA);
   return 0;
 }
@@ -726,7 +737,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
-  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged};
+  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged, 0, 0};
   for (int i = 0; i < 3; ++i) L.seg[i] = a.seg[i < a.nseg ? i : 0];
   const int ta = a.seg[0].w.type;
   bool flat_ok = true;
@@ -836,7 +847,7 @@ extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, flo
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(w->cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "tl_debug_gemv_stamps: cols %d too large", w->cols);
-  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0};
+  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0, 0, 0, 0};
   for (int i = 0; i < 3; ++i) L.seg[i] = GemvSeg{qw_view(w), y_dev};
   L.t[0] = (w->rows + 1) / 2;
   L.nsegA = 1;

@@ -184,6 +184,8 @@ struct AttnArgs {
   // != NULL: one zero-initialised counter per head group (nh / G of them; the kernel leaves them at zero). From
   // TL_ATTN_MERGE_MIN active splits on, the last workgroup of a head group merges the group's partials into record 0
   unsigned* done_cnt;
+  int zparts;  // = gridDim.z, set by the launcher (an explicit argument: gridDim comes from the hidden argument block
+               // with a scalar load of its own)
 };
 bool tl_attn_split_supported(int nh, int nkv, int hd);
 size_t tl_attn_ws_floats(int nh, int hd);

@@ -30,7 +30,8 @@ extern "C" {
 #endif
 
 /* ggml tensor type ids (reference ggml_types.h:21-42) */
-enum tl_type { TL_F32 = 0, TL_Q8_0 = 8, TL_Q4_K = 12, TL_Q6_K = 14, TL_Q8_K = 15 };
+enum tl_type { TL_F32 = 0, TL_Q8_0 = 8, TL_Q4_K = 12, TL_Q6_K = 14, TL_Q8_K = 15,
+               TL_BF16 = 30 /* tl_model_set_tensor only: widened to F32 at upload (exact) */ };
 
 typedef struct tl_qweight tl_qweight; /* one quantized [rows x cols] matrix resident in HBM */
 typedef struct tl_model tl_model;     /* a whole model + KV cache + workspaces + decode graph */

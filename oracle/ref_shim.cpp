@@ -108,6 +108,11 @@ int ref_matvec_q(int type, const void* blocks, const float* x, float* y, int row
       matvec_f32_f32_vector_cpu(w, xv, out, rows, cols);
       break;
     }
+    case GGML_TYPE_BF16: {  // what the CPU forward runs on BF16 matrices (model.cpp:583-749)
+      std::vector<uint16_t> w(static_cast<const uint16_t*>(blocks), static_cast<const uint16_t*>(blocks) + (size_t)rows * cols);
+      matvec_bf16_f32_vector_cpu(w, xv, out, rows, cols);
+      break;
+    }
     default: return -1;
   }
   std::memcpy(y, out.data(), out.size() * sizeof(float));

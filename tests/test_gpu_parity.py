@@ -417,6 +417,57 @@ def test_model_errors(E, pkg):
     m.free()
 
 
+def test_model_with_f32_and_bf16_matrices(E, pkg, oracle):
+    """The reference also loads F32 projection matrices ("fp32 exports", weight_management.cpp:889-955) and BF16 ones
+    (:888-954, run through matvec_bf16_f32_vector_cpu, utils.cpp:1046-1079, which widens each weight and then is the F32
+    mat-vec). Here: a whole layer in F32, single matrices of the other layers and lm_head in BF16, the rest Q4_K/Q6_K,
+    decoded and prefilled (token route) against the oracle holding the same values as F32; no multi-sequence step."""
+    from tinyllama_cpp_amd.capi import TlError
+    S = pkg.synth
+    cfg, tensors = S.build_model("tiny-gqa", "q4_k_m", seed=9)
+    want_t = dict(tensors)
+    def values(name):
+        t, a, r, c = tensors[name]
+        return oracle.dequantize(t, a).reshape(r, c).copy(), r, c
+    def as_bf16(w):  # truncation is enough for a test: any bf16 value is as good as another
+        return (w.view(np.uint32) >> 16).astype(np.uint16)
+    for name in [n for n in tensors if n.startswith("blk.0.") and "norm" not in n]:
+        w, r, c = values(name)
+        tensors[name] = want_t[name] = (S.F32, w, r, c)
+    for name in ("blk.1.attn_q.weight", "blk.1.ffn_gate.weight", "blk.1.attn_output.weight", "output.weight"):
+        w, r, c = values(name)
+        b = as_bf16(w)
+        tensors[name] = (S.BF16, b, r, c)
+        want_t[name] = (S.F32, (b.astype(np.uint32) << 16).view(np.float32), r, c)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, want_t)
+    toks = np.random.default_rng(6).integers(0, cfg["vocab"], 14).astype(np.int32)
+    om.reset_kv()
+    want = np.stack([om.forward(om.lookup_embedding(int(t)), pos)[1] for pos, t in enumerate(toks)])
+    got = np.stack([m.decode(int(t), pos)[0] for pos, t in enumerate(toks)])
+    assert close(got, want, LOGIT_TOL).all(), np.abs(got - want).max()
+    m.reset_kv()
+    last, allb = m.prefill(toks, 0, all_logits=True)  # 14 tokens: would be the MFMA route; F32 matrices go token by token
+    assert close(allb, want, LOGIT_TOL).all() and close(last, want[-1], LOGIT_TOL).all()
+    nxt = int(np.argmax(want[-1]))
+    ids = m.generate_greedy(nxt, len(toks), 6, 1.0, history=[nxt])
+    tok, ref_ids = nxt, []
+    for i in range(6):
+        _, lg = om.forward(om.lookup_embedding(tok), len(toks) + i)
+        tok = int(np.argmax(lg))
+        ref_ids.append(tok)
+    assert ids.tolist() == ref_ids
+    with pytest.raises(TlError, match="multi-sequence"):
+        m.batch_init(4)
+    m.free()
+    om.close()
+    bad = E.Model(cfg)
+    t, a, r, c = tensors["blk.1.attn_v.weight"]
+    with pytest.raises(TlError, match="ggml type 1;"):
+        bad.set_tensor("blk.1.attn_v.weight", 1, np.zeros((r, c), np.float16), r, c)  # F16: not a type the reference maps either
+    bad.free()
+
+
 def test_quantize_q8_k_bit_exact(E, oracle):
     """quantize_fp32_to_q8_K on the device == the oracle byte for byte (scales through the reference's own float->half
     rule, round-half-away quantization, bsums), incl. all-zero blocks, huge / tiny magnitudes and exact .5 ties."""
@@ -439,9 +490,9 @@ def test_quantize_q8_k_bit_exact(E, oracle):
         check(lib().tl_quantize_q8_k(xb.ptr, 100, ob.ptr, None))
 
 
-def test_model_with_q8k_tensors_and_f32_refusal(E, pkg, oracle):
+def test_model_with_q8k_tensors(E, pkg, oracle):
     """Q8_K matrices (in-memory only in the reference: its GGUF parser rejects them) mix with the other formats in one
-    model, through decode and the MFMA prefill; an F32 projection matrix is refused at load with a clear error."""
+    model, through decode and the MFMA prefill."""
     from tinyllama_cpp_amd.capi import TlError
     S = pkg.synth
     cfg, tensors = S.build_model("tiny", "q4_k_m", seed=4)
@@ -466,8 +517,3 @@ def test_model_with_q8k_tensors_and_f32_refusal(E, pkg, oracle):
     assert got.tolist() == ids
     m.free()
     om.close()
-    t, a, r, c = tensors["blk.0.attn_v.weight"]
-    bad = E.Model(cfg)
-    with pytest.raises(TlError, match="ggml type 0"):
-        bad.set_tensor("blk.0.attn_v.weight", S.F32, oracle.dequantize(t, a).reshape(r, c).copy(), r, c)
-    bad.free()

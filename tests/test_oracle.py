@@ -6,6 +6,8 @@ import pytest
 
 from oracle.oracle import OracleModel, Ref, Q4_K, Q6_K, Q8_0, Q8_K
 
+F32 = 0
+
 TYPES = {"q4_k": Q4_K, "q6_k": Q6_K, "q8_0": Q8_0, "q8_k": Q8_K}
 
 
@@ -161,6 +163,15 @@ def test_oracle_vs_live_reference(oracle, pkg):
         w = S.random_blocks(t, rows * cols // S.BLOCK_ELEMS[t], rng, w_std=0.03)
         x = rng.standard_normal(cols).astype(np.float32)
         assert np.array_equal(oracle.matvec_q(t, w, x, rows, cols), ref.matvec_q(t, w, x, rows, cols))
+    # F32 and BF16 matrices: the reference's BF16 mat-vec widens each weight and is then its F32 mat-vec, which is what
+    # the backend relies on when it widens BF16 tensors to F32 at upload (tl_model_set_tensor)
+    rows, cols = 24, 512
+    wf = (rng.standard_normal((rows, cols)) * 0.05).astype(np.float32)
+    x = rng.standard_normal(cols).astype(np.float32)
+    assert np.array_equal(oracle.matvec_q(F32, wf, x, rows, cols), ref.matvec_q(F32, wf, x, rows, cols))
+    wb = (wf.view(np.uint32) >> 16).astype(np.uint16)
+    wide = (wb.astype(np.uint32) << 16).view(np.float32)
+    assert np.array_equal(oracle.matvec_q(F32, wide, x, rows, cols), ref.matvec_q(30, wb, x, rows, cols))
     x = (rng.standard_normal(4096) * 7).astype(np.float32)
     w = rng.standard_normal(4096).astype(np.float32)
     assert np.array_equal(oracle.rmsnorm_vector(x, w, 1e-5), ref.rmsnorm_vector(x, w, 1e-5))

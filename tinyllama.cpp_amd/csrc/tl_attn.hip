@@ -378,11 +378,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
 // The (max, sum) pairs of all splits are loaded in one go and the partial rows eight at a time (unrolled, clamped:
 // independent loads instead of one dependent round trip per split); the sums run in split order.
 __global__ __launch_bounds__(128) void attn_combine_kernel(const float* __restrict__ ws, float* __restrict__ out, int hd,
-                                                           int seq_len, const int* __restrict__ pos_dev) {
+                                                           int seq_len, const int* __restrict__ pos_dev, int merged) {
   constexpr int NS = TL_ATTN_MAX_SPLITS;
   const int len = pos_dev ? *pos_dev + 1 : seq_len;
-  const int SL = tl_attn_split_len(len);
-  const int active = (len + SL - 1) / SL;
+  const int active = tl_attn_records(len, merged != 0);  // (1 where the split kernel merged its partials itself)
   const int h = blockIdx.x, d = threadIdx.x;
   if (d >= hd) return;
   const int recl = hd + 4;
@@ -469,7 +468,7 @@ int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s) {
 }
 
 int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s) {
-  attn_combine_kernel<<<a.nh, 128, 0, s>>>(a.ws, a.out, a.hd, a.seq_len, a.pos_dev);
+  attn_combine_kernel<<<a.nh, 128, 0, s>>>(a.ws, a.out, a.hd, a.seq_len, a.pos_dev, a.done_cnt != nullptr);
   TL_HIP(hipGetLastError());
   return 0;
 }

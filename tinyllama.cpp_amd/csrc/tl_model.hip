@@ -67,6 +67,8 @@ struct tl_model {
   float* cand_v = nullptr;     // per-slice arg-max candidates (sampling)
   int* cand_i = nullptr;
   float* attn_ws = nullptr;    // split-attention partials
+  float* xn = nullptr;         // normalised input of the unfused (F32-matrix) projections
+  bool has_f32 = false;        // some projection matrix is F32 (set by finalize): no MFMA prefill, no multi-sequence step
   bool attn_split = false;
   int* state = nullptr;  // DevState header + history ring
   int hist_cap = 0;
@@ -202,6 +204,7 @@ extern "C" int tl_model_free(tl_model* m) {
   hipFree(m->cand_v);
   hipFree(m->cand_i);
   hipFree(m->attn_ws);
+  hipFree(m->xn);
   float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all, m->pf.xpart};
   for (float* b : pbufs) hipFree(b);
   hipFree(m->pf.planes);
@@ -220,16 +223,34 @@ extern "C" int tl_model_free(tl_model* m) {
   return 0;
 }
 
+// BF16 -> F32 (exact: the bits become the upper half of the word; bfloat16_to_float32, utils.cpp:144-166)
+static std::vector<float> widen_bf16(const void* host_data, size_t n) {
+  const uint16_t* b = static_cast<const uint16_t*>(host_data);
+  std::vector<float> out(n);
+  for (size_t i = 0; i < n; ++i) {
+    const uint32_t bits = (uint32_t)b[i] << 16;
+    memcpy(&out[i], &bits, 4);
+  }
+  return out;
+}
+
 extern "C" int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, const void* host_data, int rows,
                                    int cols) {
   TL_REQUIRE(m && host_data, "tl_model_set_tensor: null argument");
   TL_REQUIRE(!m->finalized, "tl_model_set_tensor: model already finalized");
+  TL_REQUIRE(rows > 0 && cols > 0, "tl_model_set_tensor: shape %d x %d", rows, cols);
+  if (type == TL_BF16) {
+    // BF16 tensors (SafeTensors-derived files; weight_management.cpp:888-954 keeps them as uint16 and the CPU forward
+    // widens every weight on the fly, utils.cpp:1046-1079) are widened once, here, and held as F32 matrices
+    const std::vector<float> wide = widen_bf16(host_data, (size_t)rows * cols);
+    return tl_model_set_tensor(m, kind, layer, TL_F32, wide.data(), rows, cols);
+  }
   const tl_model_config& c = m->cfg;
   const int H = c.hidden_size, I = m->I_l, V = c.vocab_size;  // I: this rank's share
   const int qd = m->qd_l, kvd = m->kv_dim;
   if (kind == TL_T_ATTN_NORM || kind == TL_T_FFN_NORM || kind == TL_T_OUTPUT_NORM) {
-    // norms must be F32 tensors (weight_management.cpp:838,926,957)
-    TL_REQUIRE(type == TL_F32, "tl_model_set_tensor: norm weights must be F32 (got type %d)", type);
+    // norms must be F32 tensors (weight_management.cpp:838,926,957) or BF16 (widened above, model.cpp:84-107)
+    TL_REQUIRE(type == TL_F32, "tl_model_set_tensor: norm weights must be F32 or BF16 (got type %d)", type);
     TL_REQUIRE((size_t)rows * cols == (size_t)H, "tl_model_set_tensor: norm weight has %d x %d elements, expected %d", rows, cols, H);
     if (kind == TL_T_OUTPUT_NORM) return upload_f32(&m->out_norm, host_data, H, m->stream);
     TL_REQUIRE(layer >= 0 && layer < c.num_hidden_layers, "tl_model_set_tensor: layer %d out of range", layer);
@@ -254,11 +275,12 @@ extern "C" int tl_model_set_tensor(tl_model* m, int kind, int layer, int type, c
     TL_REQUIRE(layer >= 0 && layer < c.num_hidden_layers, "tl_model_set_tensor: layer %d out of range", layer);
     slot = &m->layers[layer].q[kind];
   }
-  // the engine's fused GEMV / MFMA launches read block formats only: an F32 matrix (which the reference would also
-  // accept, weight_management.cpp:732-960) is refused here, at load, not at the first step
-  TL_REQUIRE(type == TL_Q4_K || type == TL_Q6_K || type == TL_Q8_0 || type == TL_Q8_K,
-             "tl_model_set_tensor: kind %d has ggml type %d; the engine holds Q4_K, Q6_K, Q8_0 and Q8_K matrices (F32 only "
-             "for norm weights)", kind, type);
+  // Block formats run the fused GEMV / MFMA launches. An F32 matrix (the reference accepts them too: "transformer_cpp
+  // fp32 exports", weight_management.cpp:889-955; BF16 arrives here as F32) runs the unfused F32 route of the decode step
+  // (launch_proj below); such a model prefills token by token and has no multi-sequence step.
+  TL_REQUIRE(type == TL_F32 || type == TL_Q4_K || type == TL_Q6_K || type == TL_Q8_0 || type == TL_Q8_K,
+             "tl_model_set_tensor: kind %d has ggml type %d; the engine holds F32, BF16 (widened), Q4_K, Q6_K, Q8_0 and "
+             "Q8_K matrices", kind, type);
   TL_REQUIRE(rows == er && cols == ec,
              "tl_model_set_tensor: kind %d has shape %d x %d, config expects %d x %d (tp rank %d of %d: pass this rank's shard)",
              kind, rows, cols, er, ec, m->rank, m->tp);
@@ -471,6 +493,43 @@ static GemvArgs args_lm_head(tl_model* m) {
   return f;
 }
 
+// One projection launch of the step. Block formats: the fused GEMV as described by `a`. If a matrix of the launch is F32
+// (tl_model_set_tensor), the same computation unfused: combine of the attention partials / RMSNorm into a buffer, one
+// plain GEMV per matrix, SwiGLU: matvec_f32_f32_vector_cpu's place in model.cpp:577-749.
+static int launch_proj(tl_model* m, const GemvArgs& a, hipStream_t s) {
+  bool f32 = false;
+  for (int i = 0; i < a.nseg; ++i) f32 |= a.seg[i].w.type == TL_F32;
+  if (!f32) return tl_launch_gemv(a, s);
+  const float* x = a.x;
+  if (a.attn_ws) {
+    AttnArgs c = {};
+    c.ws = const_cast<float*>(a.attn_ws);
+    c.out = m->att;
+    c.nh = m->nh_l;
+    c.hd = a.attn_hd;
+    c.pos_dev = a.attn_pos;
+    c.done_cnt = a.attn_merged ? reinterpret_cast<unsigned*>(c.ws) : nullptr;  // (only "merged or not" is read)
+    TL_TRY(tl_launch_attn_combine(c, s));
+    x = m->att;
+  }
+  if (a.norm_w) {
+    TL_TRY(tl_launch_rmsnorm(a.x, a.norm_w, m->xn, 1, a.cols, a.eps, 1, s));
+    x = m->xn;
+  }
+  for (int i = 0; i < a.nseg; ++i) {
+    GemvArgs one = {};
+    one.seg[0] = a.seg[i];
+    one.nseg = 1;
+    one.cols = a.cols;
+    one.x = x;
+    one.resid = a.resid;
+    one.role = GEMV_GENERIC;
+    TL_TRY(tl_launch_gemv(one, s));
+  }
+  if (a.pair) TL_TRY(tl_swiglu(a.seg[0].out, a.seg[1].out, a.seg[0].out, (size_t)a.seg[0].w.rows, 0, s));
+  return 0;
+}
+
 #define TL_NCCL(expr)                                                                            \
   do {                                                                                           \
     ncclResult_t r_ = (expr);                                                                    \
@@ -525,7 +584,7 @@ static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) 
   const tl_model_config& c = m->cfg;
   const int* pos_dev = m->state + 1;
   const float scale = 1.0f / sqrtf((float)m->head_dim);
-  TL_TRY(tl_launch_gemv(args_qkv(m, l), s));
+  TL_TRY(launch_proj(m, args_qkv(m, l), s));
   PROF_MARK(1);
   if (m->attn_split) {  // RoPE + KV write + split attention in one launch
     AttnArgs t = {};
@@ -554,15 +613,15 @@ static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) 
                                  c.max_position_embeddings, scale, s));
   }
   PROF_MARK(3);
-  return tl_launch_gemv(args_attn_out(m, l), s);
+  return launch_proj(m, args_attn_out(m, l), s);
 }
 // norm + gate/up GEMV + SwiGLU, ffn_down GEMV (-> x, or the partial xp when tp > 1)
 static int enqueue_mlp_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
-  TL_TRY(tl_launch_gemv(args_gate_up(m, l), s));
+  TL_TRY(launch_proj(m, args_gate_up(m, l), s));
   PROF_MARK(5);
-  return tl_launch_gemv(args_down(m, l), s);
+  return launch_proj(m, args_down(m, l), s);
 }
-static int enqueue_head(tl_model* m, hipStream_t s) { return tl_launch_gemv(args_lm_head(m), s); }
+static int enqueue_head(tl_model* m, hipStream_t s) { return launch_proj(m, args_lm_head(m), s); }
 static int enqueue_sample(tl_model* m, hipStream_t s) {
   const int V = m->cfg.vocab_size;
   argmax_slices_kernel<<<ARGMAX_SLICES, ARGMAX_THREADS, 0, s>>>(m->logits, V, m->cand_v, m->cand_i);
@@ -775,6 +834,10 @@ extern "C" int tl_model_finalize(tl_model* m) {
   TL_HIP(hipMalloc(&m->kv_base, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers));
   TL_HIP(hipMemsetAsync(m->kv_base, 0, sizeof(float) * 2 * m->kv_layer_elems * c.num_hidden_layers, m->stream));
   TL_HIP(hipMalloc(&m->x, sizeof(float) * H));
+  m->has_f32 = m->out->type == TL_F32;
+  for (int l = 0; l < c.num_hidden_layers; ++l)
+    for (int k = 0; k < 7; ++k) m->has_f32 |= m->layers[l].q[k]->type == TL_F32;
+  if (m->has_f32) TL_HIP(hipMalloc(&m->xn, sizeof(float) * (H > (size_t)m->qd_l ? H : (size_t)m->qd_l)));
   TL_HIP(hipMalloc(&m->q, sizeof(float) * (size_t)m->qd_l));
   if (m->tp > 1) {
     TL_HIP(hipMalloc(&m->xp, sizeof(float) * H));
@@ -1114,6 +1177,7 @@ extern "C" int tl_tp_local_group_prefill(tl_model* const* ms, int n, const int* 
                "tl_tp_local_group_prefill: member %d is not rank %d of a finalized %d-way group", r, r, n);
   TL_REQUIRE(start_pos >= 0 && start_pos + num_tokens <= m0->cfg.max_position_embeddings,
              "tl_tp_local_group_prefill: positions out of range");
+  for (int r = 0; r < n; ++r) TL_REQUIRE(!ms[r]->has_f32, "tl_tp_local_group_prefill: F32 / BF16 matrices have no MFMA route");
   hipStream_t s = m0->stream;
   for (int r = 0; r < n; ++r) TL_TRY(prepare_prefill(ms[r], tokens_host, num_tokens, false, s));
   std::vector<const float*> parts(n);
@@ -1331,6 +1395,8 @@ static int batch_step(tl_model* m, int T, int* ids_dev, bool advance, float* log
 extern "C" int tl_model_batch_init(tl_model* m, int max_batch) {
   TL_REQUIRE(m && m->finalized, "tl_model_batch_init: model not finalized");
   TL_REQUIRE(m->tp == 1, "tl_model_batch_init: multi-sequence decode is not available on tensor-parallel shards");
+  TL_REQUIRE(!m->has_f32, "tl_model_batch_init: a model with F32 / BF16 projection matrices has no multi-sequence step "
+                          "(its matrices run the unfused F32 route; decode the sequences one by one)");
   TL_REQUIRE(max_batch >= 1 && max_batch <= kPrefillChunk, "tl_model_batch_init: max_batch %d outside 1..%d", max_batch,
              kPrefillChunk);
   TL_REQUIRE(tl_batch_attn_supported(m->nh_l, m->nkv_l, m->head_dim),
@@ -1523,7 +1589,8 @@ extern "C" int tl_model_prefill(tl_model* m, const int* tokens_host, int num_tok
   // (all-token logits of a vocabulary-sharded lm_head are not gathered: that request takes the token-by-token route)
   // (the T x hidden all-reduces of a sharded batched prefill are bandwidth-sized: they stay with RCCL; a group that is
   //  linked by the peer exchange only takes the token-by-token route too)
-  if (num_tokens >= m->prefill_min_batch && (m->tp == 1 || (!all_logits_host && m->comm)))
+  // (a model with F32 matrices has no MFMA route: token by token through the decode step)
+  if (num_tokens >= m->prefill_min_batch && !m->has_f32 && (m->tp == 1 || (!all_logits_host && m->comm)))
     return prefill_batched(m, tokens_host, num_tokens, start_pos, last_logits_host, all_logits_host);
   TL_TRY(upload_tokens(m, tokens_host, num_tokens, m->stream));
   TL_TRY(set_state(m, tokens_host[0], start_pos, 1.0f, nullptr, 0));

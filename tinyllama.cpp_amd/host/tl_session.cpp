@@ -113,13 +113,13 @@ Session::Session(const std::string& model_path, int device, int max_context, int
       if (!tensor_slot(t.name, &kind, &layer)) continue;
       if (layer >= config_.num_hidden_layers) continue;
       int type = (int)t.type;
-      if (type != TL_F32 && type != TL_Q8_0 && type != TL_Q4_K && type != TL_Q6_K && type != TL_Q8_K)
+      if (type != TL_F32 && type != TL_BF16 && type != TL_Q8_0 && type != TL_Q4_K && type != TL_Q6_K && type != TL_Q8_K)
         throw std::runtime_error("Session: tensor " + t.name + " has ggml type " + std::to_string(type) +
-                                 ", which this backend does not hold (F32, Q8_0, Q4_K, Q6_K, Q8_K)");
+                                 ", which this backend does not hold (F32, BF16, Q8_0, Q4_K, Q6_K, Q8_K)");
       const int cols = (int)t.cols(), rows = (int)t.rows();
       tl_check(tl_model_set_tensor(model_, kind, layer, type, t.data, rows, cols), ("tl_model_set_tensor " + t.name).c_str());
       ++stats_.tensors;
-      if (type != TL_F32) stats_.quantized_bytes += t.nbytes;
+      if (type != TL_F32 && type != TL_BF16) stats_.quantized_bytes += t.nbytes;
     }
     tl_check(tl_model_finalize(model_), "tl_model_finalize");
   } catch (...) {

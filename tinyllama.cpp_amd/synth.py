@@ -12,8 +12,9 @@ import struct
 import numpy as np
 
 F32, Q8_0, Q4_K, Q6_K, Q8_K = 0, 8, 12, 14, 15
-BLOCK_BYTES = {F32: 4, Q8_0: 34, Q4_K: 144, Q6_K: 210, Q8_K: 290}
-BLOCK_ELEMS = {F32: 1, Q8_0: 32, Q4_K: 256, Q6_K: 256, Q8_K: 256}
+BF16 = 30  # accepted by tl_model_set_tensor (widened to F32 at upload); a uint16 array
+BLOCK_BYTES = {F32: 4, Q8_0: 34, Q4_K: 144, Q6_K: 210, Q8_K: 290, BF16: 2}
+BLOCK_ELEMS = {F32: 1, Q8_0: 32, Q4_K: 256, Q6_K: 256, Q8_K: 256, BF16: 1}
 TYPE_NAMES = {F32: "F32", Q8_0: "Q8_0", Q4_K: "Q4_K", Q6_K: "Q6_K", Q8_K: "Q8_K"}
 
 

@@ -90,6 +90,27 @@ def test_session_generate_batch_matches_single_sequence_runs(H, pkg, oracle, tmp
     om.close()
 
 
+def test_session_generate_batch_context_bound_is_per_sequence(H, pkg, oracle, tmp_path):
+    """A sequence that reaches the end of the context drops out of the step's batch (api.cpp:1031-1046); the others go on
+    to the requested number of steps. (The greedy route used to cut every sequence where the longest one ended.)"""
+    S = pkg.synth
+    cfg = dict(S.SHAPES["tiny-gqa"], max_pos=48)
+    cfg, tensors = S.build_model(cfg, "q4_k_m", seed=17)
+    s = H.Session(S.write_gguf(str(tmp_path / "c.gguf"), cfg, tensors))
+    om = OracleModel(oracle, cfg, tensors)
+    rng = np.random.default_rng(5)
+    prompts = [rng.integers(3, cfg["vocab"], n).astype(np.int32) for n in (40, 5, 44)]
+    s.set_max_batch(4)
+    got = s.generate_batch(prompts, 20, temperature=0.0)
+    for p, g in zip(prompts, got):
+        n = min(20, cfg["max_pos"] - len(p) + 1)  # the first id comes from the prompt, then one per free position
+        want = om.generate(p, n, penalty=1.0, eos_id=2)
+        want = want[0] if isinstance(want, tuple) else want
+        assert np.array_equal(g, want), (len(p), g, want)
+    s.close()
+    om.close()
+
+
 def test_session_rejects_unusable_files(H, pkg, tmp_path):
     S = pkg.synth
     cfg, tensors = S.build_model("tiny", "q4_k_m", seed=13)

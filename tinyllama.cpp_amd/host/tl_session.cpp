@@ -208,11 +208,9 @@ std::vector<std::vector<int>> Session::generate_batch(const std::vector<std::vec
   const int B = (int)prompts.size(), max_pos = config_.max_position_embeddings, V = config_.vocab_size;
   std::vector<std::vector<int>> out((size_t)B);
   if (steps <= 0) return out;
-  int longest = 0;
   for (const auto& p : prompts) {
     if (p.empty()) throw std::runtime_error("Session::generate_batch: empty prompt (the reference substitutes BOS after tokenizing, api.cpp:912-915)");
     if ((int)p.size() > max_pos) throw std::runtime_error("Session::generate_batch: prompt longer than the context");
-    longest = std::max(longest, (int)p.size());
   }
   if (batch_ready_ < max_batch_size_) {  // kv_cache_.initialize_batch (api.cpp:925): once, for the session's maximum
     tl_check(tl_model_batch_init(model_, max_batch_size_), "tl_model_batch_init");
@@ -251,17 +249,36 @@ std::vector<std::vector<int>> Session::generate_batch(const std::vector<std::vec
   }
   // ---- phase 2: steps 1 .. steps-1 (api.cpp:1013-1103), bounded by the context ------------------------------------------
   if (greedy) {  // ids and positions advance on the device; a column is cut at its EOS afterwards (sequences never interact)
-    const int n_more = std::min(steps - 1, max_pos - longest);
-    if (n_more <= 0) return out;
-    std::vector<int> ids((size_t)n_more * B);
-    tl_check(tl_model_batch_generate_greedy(model_, B, cur.data(), pos.data(), seq.data(), n_more, ids.data()),
-             "tl_model_batch_generate_greedy");
-    for (int i = 0; i < B; ++i)
-      for (int k = 0; k < n_more && !done[i]; ++k) {
-        const int id = ids[(size_t)k * B + i];
-        out[i].push_back(id);
-        if (id == config_.eos_token_id) done[i] = 1;
+    // In rounds: a round runs as many steps as the active sequence closest to the end of the context still has room for;
+    // that sequence then drops out (api.cpp:1031-1046 drops it from the step's batch) and the others carry on.
+    int produced = 1;
+    while (produced < steps) {
+      std::vector<int> at, ap, as;
+      int room = max_pos;
+      for (int i = 0; i < B; ++i)
+        if (!done[i] && pos[i] < max_pos) {
+          at.push_back(cur[i]);
+          ap.push_back(pos[i]);
+          as.push_back(i);
+          room = std::min(room, max_pos - pos[i]);
+        }
+      if (at.empty()) break;
+      const int n = std::min(steps - produced, room), A = (int)at.size();
+      std::vector<int> ids((size_t)n * A);
+      tl_check(tl_model_batch_generate_greedy(model_, A, at.data(), ap.data(), as.data(), n, ids.data()),
+               "tl_model_batch_generate_greedy");
+      for (int a = 0; a < A; ++a) {
+        const int i = as[a];
+        for (int k = 0; k < n && !done[i]; ++k) {
+          const int id = ids[(size_t)k * A + a];
+          out[i].push_back(id);
+          if (id == config_.eos_token_id) done[i] = 1;
+        }
+        cur[i] = ids[(size_t)(n - 1) * A + a];
+        pos[i] += n;
       }
+      produced += n;
+    }
     return out;
   }
   std::vector<float> step_logits;

@@ -242,7 +242,7 @@ def main():
     # above are the clean numbers): kept for the non-GEMV kernels
     prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_gate_up_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_g_gate_up_traffic.json")
     if args.workload == "llama-3-8b" and world == 1 and os.path.exists(tpath):  # PMC pass of this kernel on this workload (profiles/)
         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
 
@@ -281,6 +281,16 @@ def main():
         "eager_step_us": {k: round(v[0] * 1e3, 2) for k, v in prof.items()},
         "load_s": round(t_load, 1),
     }
+    if world > 1:  # the multi-rank line describes itself at the top level (the driver keeps only this line)
+        ar = kern.get("tp_all_reduce", {})
+        out["ranks"] = world
+        out["via"] = "replicas (tensor-parallel set-up failed)" if tp_fallback else ar.get("via", "rccl")
+        out["all_reduce_us"] = ar.get("us")
+        out["all_reduces_per_step"] = 0 if tp_fallback else 2 * cfg["n_layers"]
+        out["exchange_us_per_step"] = None if tp_fallback or ar.get("us") is None else round(2 * cfg["n_layers"] * ar["us"], 1)
+        out["graph_captured"] = bool(model.graph_captured())
+        out["weight_bytes_per_token_per_rank"] = int(w_bytes)
+        out["kv_bytes_per_token_per_rank"] = int(kv_bytes)
     if SHARE_GPU and world > 1:
         out["rehearsal"] = f"{world} ranks share ONE GPU (TL_BENCH_SHARE_GPU=1): control-flow check only, the numbers are not a measurement"
 

@@ -45,6 +45,7 @@ def one(typ_name, rows, cols, out):
         check(lib().tl_debug_gemv_stamps(ws[0].h, x.ptr, y.ptr, st.ptr, C.byref(g), C.byref(wv), None), "stamps")
         check(lib().tl_device_sync(), "sync")
         a = st.to_numpy(np.uint64, (256 * 16, 10))[: g.value * wv.value]
+        slot = np.arange(len(a))[a[:, 7] > 0]  # slot = wave * grid + workgroup
         live = a[a[:, 7] > 0]
         r0, r1 = live[:, 9].astype(np.int64) * 10, live[:, 8].astype(np.int64) * 10  # ns
         base = r0.min()
@@ -66,6 +67,18 @@ def one(typ_name, rows, cols, out):
         # bytes requested between 'first step done' and 'last loads issued' = all but the first two steps of each wave
         print(f"  steady loop (first step done -> last loads issued): median {int(np.median(loop))} ns; kernel span "
               f"{int(span)} ns; whole-launch rate {blocks.nbytes / span:.0f} GB/s (stamped build)")
+        # where does the spread of the waves' end times come from: between the waves of a workgroup (one CU) or between
+        # workgroups? (decides whether handing out row groups inside a workgroup would even it out)
+        end = (r0 - base) + (live[:, 7] - live[:, 0]).astype(np.float64) / clk_med
+        wg = slot % g.value
+        if len(np.unique(wg)) > 1 and len(live) > len(np.unique(wg)):
+            means = np.array([end[wg == b].mean() for b in np.unique(wg)])
+            inner = np.array([end[wg == b].max() - end[wg == b].min() for b in np.unique(wg)])
+            rec["wave_end_spread_ns"] = {"within_workgroup_median": int(np.median(inner)), "within_workgroup_max": int(inner.max()),
+                                         "workgroup_means_min": int(means.min()), "workgroup_means_max": int(means.max()),
+                                         "all_waves_mean": int(end.mean())}
+            print(f"  wave end: spread inside a workgroup median {int(np.median(inner))} / max {int(inner.max())} ns; workgroup "
+                  f"means {int(means.min())} .. {int(means.max())} ns; mean over all waves {int(end.mean())} ns")
         recs.append(rec)
     out.extend(recs[1:])  # the first repetition carries the stamped kernel's code-cache misses
     for w in ws:

@@ -184,7 +184,8 @@ def test_rope_table_upload_matches_oracle(E, oracle):
 
 @pytest.mark.parametrize("nh,nkv,hd,npos", [(4, 2, 64, 1), (32, 4, 64, 77), (32, 8, 128, 300), (8, 8, 128, 2048),
                                             (64, 8, 128, 700), (32, 4, 64, 1500), (24, 8, 128, 33),
-                                            (32, 8, 128, 8192), (64, 8, 128, 8192)])
+                                            (32, 8, 128, 8192), (64, 8, 128, 8192),
+                                            (20, 4, 64, 200), (48, 8, 128, 500), (28, 4, 128, 90)])  # groups of 5, 6, 7
 def test_attention_decode_and_prefill(E, oracle, nh, nkv, hd, npos):
     from tinyllama_cpp_amd.capi import lib, check
     rng = np.random.default_rng(nh + npos)

@@ -434,17 +434,22 @@ int launch_hg(const AttnArgs& a_in, bool fuse, hipStream_t s) {
   return 0;
 }
 
+// query heads of a kv head served by one workgroup: the largest divisor of the group size that is <= 4 (4 for groups of
+// 4 and 8, 3 for 3 and 6, 1 for 5 and 7: then every head has its own workgroup and the K/V rows are read once per head,
+// which is what the unsplit kernel does too)
+int heads_per_workgroup(int group) {
+  for (int p = 4; p >= 1; --p)
+    if (group % p == 0) return p;
+  return 1;
+}
+
 template <int HD>
-int launch_h(const AttnArgs& a, int G, bool fuse, hipStream_t s) {
-  switch (G) {
+int launch_h(const AttnArgs& a, int P, bool fuse, hipStream_t s) {
+  switch (P) {
     case 1: return launch_hg<HD, 1>(a, fuse, s);
     case 2: return launch_hg<HD, 2>(a, fuse, s);
     case 3: return launch_hg<HD, 3>(a, fuse, s);
-    case 4: return launch_hg<HD, 4>(a, fuse, s);
-    // 8 query heads per kv head (TinyLlama): two workgroups of 4 heads per (kv head, split). K/V rows are read twice
-    // (the cache rows of such models are short), the per-row softmax work of a workgroup halves
-    case 8: return launch_hg<HD, 4>(a, fuse, s);
-    default: tl_set_error("attention: %d query heads per kv head is not supported by the split kernel", G); return 2;
+    default: return launch_hg<HD, 4>(a, fuse, s);
   }
 }
 
@@ -452,8 +457,7 @@ int launch_h(const AttnArgs& a, int G, bool fuse, hipStream_t s) {
 
 bool tl_attn_split_supported(int nh, int nkv, int hd) {
   if (nkv <= 0 || nh % nkv != 0) return false;
-  const int G = nh / nkv;
-  return (hd == 64 || hd == 128) && (G == 1 || G == 2 || G == 3 || G == 4 || G == 8);
+  return hd == 64 || hd == 128;  // any group size: see heads_per_workgroup
 }
 
 size_t tl_attn_ws_floats(int nh, int hd) { return (size_t)nh * TL_ATTN_MAX_SPLITS * (hd + 4); }
@@ -463,8 +467,8 @@ int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s) {
   TL_REQUIRE(tl_attn_split_supported(a.nh, a.nkv, a.hd), "attention: unsupported head configuration %d/%d/%d", a.nh,
              a.nkv, a.hd);
   TL_REQUIRE(a.ws, "attention: workspace missing");
-  const int G = a.nh / a.nkv;
-  return a.hd == 64 ? launch_h<64>(a, G, fuse, s) : launch_h<128>(a, G, fuse, s);
+  const int P = heads_per_workgroup(a.nh / a.nkv);
+  return a.hd == 64 ? launch_h<64>(a, P, fuse, s) : launch_h<128>(a, P, fuse, s);
 }
 
 int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s) {

@@ -77,6 +77,13 @@ __device__ __forceinline__ T ldg(const uint8_t* base, unsigned byte_off) {
   typedef const T __attribute__((address_space(1))) * gptr;
   return __builtin_nontemporal_load((gptr)(unsigned long long)(base + byte_off));
 }
+// cached load at a wave-uniform base + 32-bit per-lane byte offset (scalar base + vector offset addressing: no 64-bit
+// vector arithmetic per load)
+template <typename T>
+__device__ __forceinline__ T ldc(const void* base, unsigned byte_off) {
+  typedef const T __attribute__((address_space(1))) * gptr;
+  return *(gptr)(unsigned long long)(static_cast<const uint8_t*>(base) + byte_off);
+}
 __device__ __forceinline__ float ldg_f32(const float* p) {
   typedef const float __attribute__((address_space(1))) * gptr;
   return *(gptr)(unsigned long long)p;
@@ -96,9 +103,13 @@ template <>
 struct Chunk<TL_Q4_K> {
   u32x4 a, b;  // payload, super-block header
   __device__ __forceinline__ void load(const QW& w, int row, unsigned c) {
-    const size_t r = (size_t)row, cols = (size_t)w.cols;
-    a = ldg<u32x4>(w.p0 + r * (cols >> 1), c * 16u);
-    b = ldg<u32x4>(w.p1 + r * (cols >> 4), (c >> 3) * 16u);
+    // the row's byte offset inside a plane is a 32-bit product (tl_qweight_upload refuses planes of 4 GiB and more)
+    // added to the 64-bit plane base: three scalar instructions per plane; the full 64-bit product cost ten in front of
+    // a wave's first weight load. (Carrying the row offset in the LANE offset instead was measured slower: it puts a
+    // vector add per load into the steady loop, whose VALU is the scarce resource.)
+    const unsigned r = (unsigned)row, cols = (unsigned)w.cols;
+    a = ldg<u32x4>(w.p0 + (size_t)(r * (cols >> 1)), c * 16u);
+    b = ldg<u32x4>(w.p1 + (size_t)(r * (cols >> 4)), (c >> 3) * 16u);
   }
   // Nibbles never become integers-to-convert: a masked dword IS two fp16 subnormals (n * 2^-24 in each half when
   // the nibble sits in bits 0-3 of the half, n * 2^-20 in bits 4-7), and v_fma_mix_f32 multiplies an fp16 half by an
@@ -135,11 +146,11 @@ struct Chunk<TL_Q6_K> {
   u32x2 h;  // qh'
   unsigned sc, d;
   __device__ __forceinline__ void load(const QW& w, int row, unsigned c) {
-    const size_t r = (size_t)row, cols = (size_t)w.cols;
-    a = ldg<u32x4>(w.p0 + r * (cols >> 1), c * 16u);
-    h = ldg<u32x2>(w.p1 + r * (cols >> 2), c * 8u);
-    sc = ldg<unsigned short>(w.p2 + r * (cols >> 4), c * 2u);
-    d = ldg<unsigned short>(w.p3 + r * (cols >> 7), (c >> 3) * 2u);
+    const unsigned r = (unsigned)row, cols = (unsigned)w.cols;  // (32-bit offsets: see Chunk<TL_Q4_K>::load)
+    a = ldg<u32x4>(w.p0 + (size_t)(r * (cols >> 1)), c * 16u);
+    h = ldg<u32x2>(w.p1 + (size_t)(r * (cols >> 2)), c * 8u);
+    sc = ldg<unsigned short>(w.p2 + (size_t)(r * (cols >> 4)), c * 2u);
+    d = ldg<unsigned short>(w.p3 + (size_t)(r * (cols >> 7)), (c >> 3) * 2u);
   }
   __device__ __forceinline__ float dot(const float* x, float s0, float s1, int) const {
     float acc[2];
@@ -170,11 +181,11 @@ struct ChunkQ8 {
   u32x4 a, b;
   unsigned d;
   __device__ __forceinline__ void load(const QW& w, int row, unsigned c) {
-    const size_t r = (size_t)row, cols = (size_t)w.cols;
-    a = ldg<u32x4>(w.p0 + r * cols, c * 32u);
-    b = ldg<u32x4>(w.p0 + r * cols, c * 32u + 16u);
-    d = TYPE == TL_Q8_0 ? ldg<unsigned short>(w.p1 + r * (cols >> 4), c * 2u)
-                        : ldg<unsigned short>(w.p1 + r * (cols >> 7), (c >> 3) * 2u);
+    const unsigned r = (unsigned)row, cols = (unsigned)w.cols;  // (32-bit offsets: see Chunk<TL_Q4_K>::load)
+    a = ldg<u32x4>(w.p0 + (size_t)(r * cols), c * 32u);
+    b = ldg<u32x4>(w.p0 + (size_t)(r * cols), c * 32u + 16u);
+    d = TYPE == TL_Q8_0 ? ldg<unsigned short>(w.p1 + (size_t)(r * (cols >> 4)), c * 2u)
+                        : ldg<unsigned short>(w.p1 + (size_t)(r * (cols >> 7)), (c >> 3) * 2u);
   }
   __device__ __forceinline__ float dot(const float* x, float s0, float s1, int) const {
     float a0 = 0.f, a1 = 0.f;

@@ -107,17 +107,16 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
     xattn_issue(a, i, 0, r.active, r.ao, r.am, r.al);
     return;
   }
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(a.x);
-  const f32x4* w4 = reinterpret_cast<const f32x4*>(a.norm_w ? a.norm_w : a.x);
+  const void* wbase = a.norm_w ? a.norm_w : a.x;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = threadIdx.x + k * a.nthr;
-    r.v[k] = x4[i < n4 ? i : n4 - 1];
+    r.v[k] = ldc<f32x4>(a.x, (unsigned)(i < n4 ? i : n4 - 1) * 16u);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int i = threadIdx.x + k * a.nthr;
-    r.g[k] = w4[i < n4 ? i : n4 - 1];
+    r.g[k] = ldc<f32x4>(wbase, (unsigned)(i < n4 ? i : n4 - 1) * 16u);
   }
 }
 __device__ __forceinline__ float ssq4(f32x4 t) { return (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]); }
@@ -151,8 +150,7 @@ __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r,
       float* dst = xs + (idx >> 5) * XS_STRIDE;
       *reinterpret_cast<f32x4*>(dst + (idx & 31)) = t;
       float sm4 = (t[0] + t[1]) + (t[2] + t[3]);
-      sm4 += __shfl_xor(sm4, 1);
-      sm4 += __shfl_xor(sm4, 2);
+      sm4 = dpp_add<0x4E, 0xf>(dpp_add<0xB1, 0xf>(sm4));  // quad sum in every lane of the quad (DPP, no LDS path)
       if ((i & 3) == 0) dst[32 + ((i >> 2) & 1)] = sm4;
     }
     __syncthreads();
@@ -183,8 +181,7 @@ __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r,
     *reinterpret_cast<f32x4*>(dst + (idx & 31)) = t;
     // 4 consecutive threads cover 16 consecutive x: their sum is one of the chunk's two half sums
     float s = (t[0] + t[1]) + (t[2] + t[3]);
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
+    s = dpp_add<0x4E, 0xf>(dpp_add<0xB1, 0xf>(s));  // quad sum in every lane of the quad (DPP, no LDS path)
     if ((i & 3) == 0) dst[32 + ((i >> 2) & 1)] = s;
   };
   // n4 is a multiple of 8 and blockDim of 64, so quads of threads are all-in or all-out of every branch

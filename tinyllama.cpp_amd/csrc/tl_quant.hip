@@ -153,6 +153,10 @@ int tl_qweight_build(int type, const void* host_blocks, int rows, int cols, tl_q
   TL_REQUIRE(cols % col_mult == 0, "tl_qweight: cols (%d) must be a multiple of %d for type %d", cols, col_mult,
              type);
   PlaneSizes ps = plane_sizes(type, (size_t)rows, (size_t)cols);
+  // (the GEMV / GEMM kernels address a plane with 32-bit byte offsets; + 1280: the whole-KiB over-read slack)
+  TL_REQUIRE(type == TL_F32 || ps.s0 + 1280 < (1ull << 32),
+             "tl_qweight: a %d x %d matrix of type %d has a plane of %zu bytes (4 GiB and more are not addressable)", rows,
+             cols, type, ps.s0);
   uint8_t* base = static_cast<uint8_t*>(w->base);
   w->type = type;
   w->rows = rows;

@@ -50,6 +50,34 @@ int tlh_session_generate_batch(tlh_session* s, const int* prompt_ids, const int*
 /* load statistics: tensors uploaded, quantized bytes taken from the mapping, seconds for open() */
 int tlh_session_load_stats(const tlh_session* s, uint64_t* tensors, uint64_t* quantized_bytes, double* seconds);
 
+/* ---- tokenizer : Tokenizer (tokenizer.h:27-235) for models that come as GGUF files; tl_tokenizer.hpp, no GPU involved.
+ * PARITY UNPINNED (the reference's tokenizer.cpp needs Boost and cannot be built in this image, and the reference holds no
+ * tokenizer vectors): tests compare with oracle/tokenizer_oracle.py. Text is bytes + length both ways (a decoded byte
+ * token may be 0); on output *n_out is the full length, of which at most `cap` bytes / ids were written. ---- */
+typedef struct tlh_tokenizer tlh_tokenizer;
+/* Tokenizer(gguf_data, config) (tokenizer.cpp:516). family_override: 0 = as model_config.cpp:221-253 decides from the
+ * file; 1 = Llama-2 / TinyLlama SentencePiece, 2 = Llama-3 tiktoken, 3 = word level */
+int tlh_tokenizer_from_gguf(const tlh_gguf* g, int family_override, tlh_tokenizer** out);
+int tlh_tokenizer_close(tlh_tokenizer* t);
+/* out[0..5] = family, vocabulary size, bos, eos, unk, pad id */
+int tlh_tokenizer_info(const tlh_tokenizer* t, int out[6]);
+/* Tokenizer::encode (tokenizer.cpp:1141) */
+int tlh_tokenizer_encode(const tlh_tokenizer* t, const char* text, size_t text_len, int add_bos, int add_eos, int* ids,
+                         int cap, int* n_out);
+/* Tokenizer::decode (tokenizer.cpp:1412) */
+int tlh_tokenizer_decode(const tlh_tokenizer* t, const int* ids, int n_ids, int skip_special_tokens, char* buf, size_t cap,
+                         size_t* n_out);
+/* Tokenizer::apply_chat_template (tokenizer.cpp:1663) */
+int tlh_tokenizer_apply_chat_template(const tlh_tokenizer* t, const char* user, size_t user_len, const char* system,
+                                      size_t system_len, char* buf, size_t cap, size_t* n_out);
+/* the prompt TinyLlamaSession::generate encodes (api.cpp:505-572) */
+int tlh_tokenizer_format_prompt(const tlh_tokenizer* t, const char* user, size_t user_len, const char* system,
+                                size_t system_len, int apply_q_a_format, char* buf, size_t cap, size_t* n_out);
+/* TinyLlamaSession::generate on text (api.h:59-66): format, encode, generate, decode. Fails when the file has no tokenizer. */
+int tlh_session_generate_text(tlh_session* s, const char* prompt, size_t prompt_len, int steps, float temperature, int top_k,
+                              float top_p, const char* system_prompt, size_t system_len, int apply_q_a_format, char* buf,
+                              size_t cap, size_t* n_out);
+
 /* ---- host-side sampler pieces (api.cpp:86-97, 126-216), exposed for parity tests; no GPU involved ---- */
 int tlh_apply_repetition_penalty(float* logits, int n, const int* generated, int n_generated, float penalty);
 /* candidate ids and renormalised probabilities the sampler draws from; *n_out <= cap entries written */

@@ -136,3 +136,58 @@ def test_tl_run_binary(pkg, oracle, tmp_path):
     want = want[0] if isinstance(want, tuple) else want
     assert got == list(map(int, want))
     om.close()
+
+
+def test_session_generates_from_text(H, pkg, oracle, tmp_path):
+    """TinyLlamaSession::generate as the reference declares it (text in, text out; api.cpp:488-835): the file's tokenizer
+    formats and encodes the prompt, the ids run through the same loop as above, the generated ids are decoded without
+    special tokens. Word-level and SentencePiece-style vocabularies (tokenizer parity itself: tests/test_tokenizer_cpu.py,
+    unpinned); and tl_run --prompt."""
+    import test_tokenizer_cpu as TT
+    from oracle import tokenizer_oracle as TO
+    S = pkg.synth
+    sp = TT.spm_parts()
+    for family in ("word", "spm"):
+        cfg = dict(S.SHAPES["tiny"])
+        if family == "word":
+            tokens = [b"<pad>", b"<unk>", b"<s>", b"</s>"] + [b"w%d" % i for i in range(4, cfg["vocab"])]
+            kvs = S.tokenizer_kvs(tokens, model="word", bos=2, eos=3, unk=1, pad=0)
+            o = TO.TokenizerOracle(TO.WORD_LEVEL, tokens, bos=2, eos=3, unk=1, pad=0)
+            prompt, system, eos = b"W10 w20  w33 zzz", b"", 3
+        else:
+            pad = -len(sp["tokens"]) % 64  # unused entries up to a multiple of 64 rows for the embedding / output matrices
+            tokens = sp["tokens"] + [b"[unused%d]" % i for i in range(pad)]
+            scores, types = sp["scores"] + [-1e4 - i for i in range(pad)], sp["token_types"] + [1] * pad
+            cfg["vocab"] = len(tokens)
+            kvs = S.tokenizer_kvs(tokens, scores=scores, token_types=types, bos=1, eos=2, unk=0)
+            o = TO.TokenizerOracle(TO.LLAMA_SENTENCEPIECE, tokens, scores=scores, token_types=types, bos=1, eos=2, unk=0)
+            prompt, system, eos = b"what is the answer ?", b"be brief", 2
+        _, tensors = S.build_model(cfg, "q4_k_m", seed=21)
+        path = S.write_gguf(str(tmp_path / f"{family}.gguf"), cfg, tensors, extra_kvs=kvs)
+        s = H.Session(path)
+        om = OracleModel(oracle, cfg, tensors)
+        want_by_qa = {}
+        for qa in (False, True):
+            ids = o.encode(o.format_prompt(prompt, system, qa), True, False)
+            assert len(ids) >= 3
+            want = om.generate(np.array(ids, np.int32), 12, penalty=1.3, eos_id=eos)
+            want_by_qa[qa] = [int(i) for i in (want[0] if isinstance(want, tuple) else want)]
+            assert s.generate_text(prompt, 12, temperature=0.0, system_prompt=system, apply_q_a_format=qa) == \
+                o.decode(want_by_qa[qa], True), (family, qa)
+        s.close()
+        om.close()
+        if family == "spm":
+            exe = os.path.join(ROOT, "tinyllama.cpp_amd", "host", "tl_run")
+            out = subprocess.run([exe, path, "--prompt", prompt.decode(), "--system", system.decode(), "--steps", "12"],
+                                 capture_output=True, timeout=120)
+            assert out.returncode == 0, out.stderr
+            first, rest = out.stdout.split(b"\n", 1)
+            assert json.loads(first)["generated"] == want_by_qa[False]
+            assert rest[:-1] == o.decode(want_by_qa[False], True)
+    # a file without tokenizer metadata: the text entry point refuses as the reference does (api.cpp:490-492)
+    cfg, tensors = S.build_model("tiny", "q4_k_m", seed=13)
+    s = H.Session(S.write_gguf(str(tmp_path / "plain.gguf"), cfg, tensors))
+    with pytest.raises(H.TlHostError, match="Model or tokenizer not loaded"):
+        s.generate_text(b"hello", 4)
+    s.close()
+

@@ -157,7 +157,15 @@ void GGUFFile::open(const std::string& path) {
           const size_t es = scalar_size(v.array_type);
           if (es == 0) throw std::runtime_error("GGUF: array of unsupported element type in key " + key);
           if (v.array_count > size_ / es) throw std::runtime_error("GGUF: array longer than the file in key " + key);
-          c.skip((size_t)v.array_count * es);
+          if (key == "tokenizer.ggml.scores" && v.array_type == VT_F32) {
+            v.floats.resize((size_t)v.array_count);
+            for (auto& f : v.floats) f = c.get<float>();
+          } else if (key == "tokenizer.ggml.token_type" && (v.array_type == VT_U32 || v.array_type == VT_I32)) {
+            v.ints.resize((size_t)v.array_count);
+            for (auto& t : v.ints) t = c.get<int32_t>();  // (U32 values are reinterpreted, as the reference does)
+          } else {
+            c.skip((size_t)v.array_count * es);
+          }
         }
       } else {
         v = read_scalar(c, t);

@@ -29,6 +29,8 @@ struct GGUFValue {
   uint32_t array_type = 0;   // ARRAY: element type and count (elements are skipped, except string arrays)
   uint64_t array_count = 0;
   std::vector<std::string> strings;  // ARRAY of strings (tokenizer.ggml.tokens / merges)
+  std::vector<float> floats;         // tokenizer.ggml.scores (F32 array), gguf_parser.cpp:255-266
+  std::vector<int32_t> ints;         // tokenizer.ggml.token_type (U32 or I32 array), gguf_parser.cpp:268-292
   bool as_integer(int64_t* out) const;  // any integral kind (model_config.cpp:89-147 accepts every integral type)
   bool as_double(double* out) const;
 };

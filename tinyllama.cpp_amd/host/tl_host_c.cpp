@@ -39,6 +39,16 @@ struct tlh_gguf {
 struct tlh_session {
   tlhost::Session* s = nullptr;
 };
+struct tlh_tokenizer {
+  tlhost::Tokenizer* t = nullptr;
+};
+namespace {
+std::string str_arg(const char* p, size_t n) { return p && n ? std::string(p, n) : std::string(); }
+void copy_bytes(const std::string& s, char* buf, size_t cap, size_t* n_out) {
+  if (buf && cap) memcpy(buf, s.data(), s.size() < cap ? s.size() : cap);
+  *n_out = s.size();
+}
+}  // namespace
 
 extern "C" {
 
@@ -177,6 +187,64 @@ int tlh_session_load_stats(const tlh_session* s, uint64_t* tensors, uint64_t* qb
   if (qbytes) *qbytes = st.quantized_bytes;
   if (seconds) *seconds = st.seconds;
   return 0;
+}
+
+int tlh_tokenizer_from_gguf(const tlh_gguf* g, int family_override, tlh_tokenizer** out) {
+  if (!g || !out || family_override < 0 || family_override > 3) return fail("tlh_tokenizer_from_gguf: bad argument");
+  tlh_tokenizer* h = new tlh_tokenizer();
+  const int rc = guarded([&] { h->t = new tlhost::Tokenizer(g->f, (tlhost::TokenizerFamily)family_override); });
+  if (rc != 0) {
+    delete h;
+    return rc;
+  }
+  *out = h;
+  return 0;
+}
+int tlh_tokenizer_close(tlh_tokenizer* t) {
+  if (t) delete t->t;
+  delete t;
+  return 0;
+}
+int tlh_tokenizer_info(const tlh_tokenizer* t, int out[6]) {
+  if (!t || !out) return fail("tlh_tokenizer_info: null argument");
+  const int v[6] = {(int)t->t->family(), t->t->vocab_size(),   t->t->bos_token_id(),
+                    t->t->eos_token_id(), t->t->unk_token_id(), t->t->pad_token_id()};
+  memcpy(out, v, sizeof(v));
+  return 0;
+}
+int tlh_tokenizer_encode(const tlh_tokenizer* t, const char* text, size_t text_len, int add_bos, int add_eos, int* ids,
+                         int cap, int* n_out) {
+  if (!t || !n_out || (text_len > 0 && !text) || cap < 0) return fail("tlh_tokenizer_encode: bad argument");
+  return guarded([&] {
+    const std::vector<int> v = t->t->encode(str_arg(text, text_len), add_bos != 0, add_eos != 0);
+    const size_t k = v.size() < (size_t)cap ? v.size() : (size_t)cap;
+    if (ids && k) memcpy(ids, v.data(), sizeof(int) * k);
+    *n_out = (int)v.size();
+  });
+}
+int tlh_tokenizer_decode(const tlh_tokenizer* t, const int* ids, int n_ids, int skip_special, char* buf, size_t cap,
+                         size_t* n_out) {
+  if (!t || !n_out || n_ids < 0 || (n_ids > 0 && !ids)) return fail("tlh_tokenizer_decode: bad argument");
+  return guarded([&] { copy_bytes(t->t->decode(std::vector<int>(ids, ids + n_ids), skip_special != 0), buf, cap, n_out); });
+}
+int tlh_tokenizer_apply_chat_template(const tlh_tokenizer* t, const char* user, size_t user_len, const char* system,
+                                      size_t system_len, char* buf, size_t cap, size_t* n_out) {
+  if (!t || !n_out) return fail("tlh_tokenizer_apply_chat_template: null argument");
+  return guarded([&] { copy_bytes(t->t->apply_chat_template(str_arg(user, user_len), str_arg(system, system_len)), buf, cap, n_out); });
+}
+int tlh_tokenizer_format_prompt(const tlh_tokenizer* t, const char* user, size_t user_len, const char* system,
+                                size_t system_len, int qa, char* buf, size_t cap, size_t* n_out) {
+  if (!t || !n_out) return fail("tlh_tokenizer_format_prompt: null argument");
+  return guarded([&] { copy_bytes(t->t->format_prompt(str_arg(user, user_len), str_arg(system, system_len), qa != 0), buf, cap, n_out); });
+}
+int tlh_session_generate_text(tlh_session* s, const char* prompt, size_t prompt_len, int steps, float temperature, int top_k,
+                              float top_p, const char* system_prompt, size_t system_len, int qa, char* buf, size_t cap,
+                              size_t* n_out) {
+  if (!s || !n_out) return fail("tlh_session_generate_text: null argument");
+  return guarded([&] {
+    copy_bytes(s->s->generate(str_arg(prompt, prompt_len), steps, temperature, top_k, top_p, str_arg(system_prompt, system_len), qa != 0),
+               buf, cap, n_out);
+  });
 }
 
 int tlh_apply_repetition_penalty(float* logits, int n, const int* generated, int n_generated, float penalty) {

@@ -92,6 +92,8 @@ Session::Session(const std::string& model_path, int device, int max_context, int
   if (max_context > 0 && max_context < config_.max_position_embeddings) config_.max_position_embeddings = max_context;
   if (max_batch_size < 1) throw std::runtime_error("Session: max_batch_size must be >= 1");
   max_batch_size_ = max_batch_size;
+  if (const GGUFValue* toks = file.meta("tokenizer.ggml.tokens"))
+    if (!toks->strings.empty()) tokenizer_.reset(new Tokenizer(file));
   tl_check(tl_init(device), "tl_init");
   tl_model_config mc = {};
   mc.hidden_size = config_.hidden_size;
@@ -192,6 +194,33 @@ std::vector<int> Session::generate(const std::vector<int>& prompt, int steps, fl
     if (next == config_.eos_token_id) break;
   }
   return generated;
+}
+
+std::string Session::generate(const std::string& prompt, int steps, float temperature, int top_k, float top_p,
+                              const std::string& system_prompt, bool apply_q_a_format) {
+  if (!model_ || !tokenizer_) throw std::runtime_error("Model or tokenizer not loaded.");
+  const std::vector<int> ids = tokenizer_->encode(tokenizer_->format_prompt(prompt, system_prompt, apply_q_a_format), true, false);
+  if (ids.empty()) return "";  // api.cpp:576-580
+  return tokenizer_->decode(generate(ids, steps, temperature, top_k, top_p), true);
+}
+
+std::vector<std::string> Session::generate_batch(const std::vector<std::string>& prompts, int steps, float temperature,
+                                                 int top_k, float top_p, const std::string& system_prompt,
+                                                 bool apply_q_a_format) {
+  if (prompts.empty()) throw std::runtime_error("Cannot process empty prompts vector for batch generation.");
+  if ((int)prompts.size() > max_batch_size_)
+    throw std::runtime_error("Batch size " + std::to_string(prompts.size()) + " exceeds maximum batch size " +
+                             std::to_string(max_batch_size_));
+  if (!model_ || !tokenizer_) throw std::runtime_error("Model or tokenizer not loaded for batch generation.");
+  std::vector<std::vector<int>> ids(prompts.size());
+  for (size_t i = 0; i < prompts.size(); ++i) {
+    ids[i] = tokenizer_->encode(tokenizer_->format_prompt(prompts[i], system_prompt, apply_q_a_format, true), true, false);
+    if (ids[i].empty()) ids[i].push_back(tokenizer_->bos_token_id());  // api.cpp:911-914
+  }
+  const std::vector<std::vector<int>> out = generate_batch(ids, steps, temperature, top_k, top_p);
+  std::vector<std::string> text(out.size());
+  for (size_t i = 0; i < out.size(); ++i) text[i] = tokenizer_->decode(out[i], true);  // api.cpp:1107
+  return text;
 }
 
 void Session::set_max_batch_size(int n) {

@@ -1,16 +1,19 @@
 // tl_session.hpp — the C++ host above the C-ABI (include/tlhip.h): what TinyLlamaSession / TinyLlamaModel keep doing on
 // the host once the CUDA backend is replaced by libtlhip.so.
 //
-// Mirrors tinyllama::TinyLlamaSession (api.h:26-143) on TOKEN IDS: the tokenizer (tokenizer.cpp, needs Boost) is out of
-// scope, so generate() takes and returns ids where the reference takes and returns text. Same argument meaning
-// (steps, temperature, top_k, top_p), same loop (api.cpp:585-813), same error convention (std::runtime_error).
+// Mirrors tinyllama::TinyLlamaSession (api.h:26-143). generate() / generate_batch() exist twice: on TOKEN IDS (the part
+// whose parity is pinned), and on text as in the reference, through tl_tokenizer.hpp (a restatement of tokenizer.cpp
+// without Boost; parity unpinned, see there). Same argument meaning (steps, temperature, top_k, top_p, system prompt,
+// Q/A hint), same loop (api.cpp:585-813), same error convention (std::runtime_error).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <random>
 #include <string>
 #include <vector>
 
 #include "tl_gguf.hpp"
+#include "tl_tokenizer.hpp"
 #include "tlhip.h"
 
 namespace tlhost {
@@ -54,6 +57,17 @@ class Session {
   std::vector<std::vector<int>> generate_batch(const std::vector<std::vector<int>>& prompts, int steps = 128,
                                                float temperature = 0.1f, int top_k = 40, float top_p = 0.9f);
 
+  // the reference's own signatures (api.h:59-78): the prompt is formatted (Tokenizer::format_prompt, api.cpp:505-572),
+  // encoded with BOS, generated from as above, and the generated ids are decoded without special tokens. Throw
+  // std::runtime_error when the file carries no tokenizer ("Model or tokenizer not loaded.", api.cpp:491).
+  std::string generate(const std::string& prompt, int steps = 128, float temperature = 0.1f, int top_k = 40,
+                       float top_p = 0.9f, const std::string& system_prompt = "", bool apply_q_a_format = false);
+  std::vector<std::string> generate_batch(const std::vector<std::string>& prompts, int steps = 128, float temperature = 0.1f,
+                                          int top_k = 40, float top_p = 0.9f, const std::string& system_prompt = "",
+                                          bool apply_q_a_format = false);
+  // null when the file has no tokenizer.ggml.tokens (the synthetic test models)
+  const Tokenizer* get_tokenizer() const { return tokenizer_.get(); }
+
   void set_max_batch_size(int n);
   int get_max_batch_size() const { return max_batch_size_; }
   void set_repetition_penalty(float p) { repetition_penalty_ = p; }
@@ -66,6 +80,7 @@ class Session {
  private:
   ModelConfig config_;
   tl_model* model_ = nullptr;
+  std::unique_ptr<Tokenizer> tokenizer_;
   std::mt19937 rng_{std::random_device{}()};
   float repetition_penalty_ = 1.3f;  // api.h:135
   int max_batch_size_ = 1;           // api.h:142

@@ -1,4 +1,4 @@
-"""ctypes view of the C++ host layer (libtlhost.so, include/tlhost.h): GGUF reader, Session, host-side sampler.
+"""ctypes view of the C++ host layer (libtlhost.so, include/tlhost.h): GGUF reader, tokenizer, Session, host-side sampler.
 
 The host layer is C++ (tinyllama.cpp_amd/host); this module only exists so that the tests can drive it. It has no
 fallback: a missing library raises."""
@@ -33,6 +33,15 @@ SIGNATURES = {
     "tlh_session_set_max_batch": [_vp, _i],
     "tlh_session_generate_batch": [_vp, _vp, _vp, _i, _i, _f, _i, _f, _vp, _vp],
     "tlh_session_load_stats": [_vp, _vp, _vp, _vp],
+    "tlh_tokenizer_from_gguf": [_vp, _i, _vp],
+    "tlh_tokenizer_close": [_vp],
+    "tlh_tokenizer_info": [_vp, _vp],
+    "tlh_tokenizer_encode": [_vp, C.c_char_p, C.c_size_t, _i, _i, _vp, _i, _vp],
+    "tlh_tokenizer_decode": [_vp, _vp, _i, _i, _vp, C.c_size_t, _vp],
+    "tlh_tokenizer_apply_chat_template": [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, _vp, C.c_size_t, _vp],
+    "tlh_tokenizer_format_prompt": [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, _i, _vp, C.c_size_t, _vp],
+    "tlh_session_generate_text": [_vp, C.c_char_p, C.c_size_t, _i, _f, _i, _f, C.c_char_p, C.c_size_t, _i, _vp,
+                                  C.c_size_t, _vp],
     "tlh_apply_repetition_penalty": [_vp, _i, _vp, _i, _f],
     "tlh_sampling_distribution": [_vp, _i, _f, _i, _f, _vp, _vp, _i, _vp],
     "tlh_sample": [_vp, _i, _f, _i, _f, C.c_uint32, _vp],
@@ -112,6 +121,73 @@ class GGUF:
         return d
 
 
+def _bytes_out(call, what, cap=4096):
+    """Run call(buf, cap, byref(n)) growing the buffer until the whole result fits."""
+    while True:
+        buf, n = C.create_string_buffer(cap), C.c_size_t(0)
+        check(call(buf, cap, C.byref(n)), what)
+        if n.value <= cap:
+            return buf.raw[: n.value]
+        cap = n.value
+
+
+def _b(x):
+    return x.encode() if isinstance(x, str) else bytes(x)
+
+
+class Tokenizer:
+    """tlhost::Tokenizer (host/tl_tokenizer.hpp) over the C view. Text goes in as str or bytes and comes out as bytes."""
+    FAMILIES = ("unknown", "llama_sentencepiece", "llama3_tiktoken", "word_level")
+
+    def __init__(self, gguf, family=0):
+        self._own = None
+        if not isinstance(gguf, GGUF):
+            gguf = self._own = GGUF(gguf)
+        h = C.c_void_p()
+        check(lib().tlh_tokenizer_from_gguf(gguf.h, int(family), C.byref(h)), "tlh_tokenizer_from_gguf")
+        self.h = h.value
+        if self._own:  # the tokenizer copies what it needs out of the file
+            self._own.close()
+
+    def close(self):
+        if self.h:
+            lib().tlh_tokenizer_close(self.h)
+            self.h = None
+
+    def info(self):
+        out = (C.c_int * 6)()
+        check(lib().tlh_tokenizer_info(self.h, out), "tlh_tokenizer_info")
+        return dict(zip(("family", "vocab", "bos", "eos", "unk", "pad"), list(out)))
+
+    def encode(self, text, add_bos=True, add_eos=False):
+        t = _b(text)
+        cap = 2 * len(t) + 16
+        while True:
+            ids, n = np.zeros(cap, np.int32), C.c_int(0)
+            check(lib().tlh_tokenizer_encode(self.h, t, len(t), int(add_bos), int(add_eos), ids.ctypes.data, cap, C.byref(n)),
+                  "tlh_tokenizer_encode")
+            if n.value <= cap:
+                return ids[: n.value].tolist()
+            cap = n.value
+
+    def decode(self, ids, skip_special_tokens=True):
+        a = np.ascontiguousarray(ids, np.int32)
+        return _bytes_out(lambda buf, cap, n: lib().tlh_tokenizer_decode(self.h, a.ctypes.data if a.size else None, a.size,
+                                                                         int(skip_special_tokens), buf, cap, n),
+                          "tlh_tokenizer_decode")
+
+    def apply_chat_template(self, user, system=b""):
+        u, s = _b(user), _b(system)
+        return _bytes_out(lambda buf, cap, n: lib().tlh_tokenizer_apply_chat_template(self.h, u, len(u), s, len(s), buf, cap, n),
+                          "tlh_tokenizer_apply_chat_template")
+
+    def format_prompt(self, user, system=b"", apply_q_a_format=False):
+        u, s = _b(user), _b(system)
+        return _bytes_out(lambda buf, cap, n: lib().tlh_tokenizer_format_prompt(self.h, u, len(u), s, len(s),
+                                                                                int(apply_q_a_format), buf, cap, n),
+                          "tlh_tokenizer_format_prompt")
+
+
 class Session:
     def __init__(self, path, device=0, max_context=0):
         h = C.c_void_p()
@@ -136,6 +212,13 @@ class Session:
         check(lib().tlh_session_generate(self.h, p.ctypes.data, p.size, int(steps), float(temperature), int(top_k),
                                          float(top_p), out.ctypes.data, out.size, C.byref(n)), "tlh_session_generate")
         return out[: n.value]
+
+    def generate_text(self, prompt, steps=128, temperature=0.1, top_k=40, top_p=0.9, system_prompt=b"", apply_q_a_format=False):
+        """TinyLlamaSession::generate as the reference declares it: text in, text (bytes) out."""
+        p, s = _b(prompt), _b(system_prompt)
+        return _bytes_out(lambda buf, cap, n: lib().tlh_session_generate_text(
+            self.h, p, len(p), int(steps), float(temperature), int(top_k), float(top_p), s, len(s), int(apply_q_a_format),
+            buf, cap, n), "tlh_session_generate_text", cap=4096 + 256 * max(int(steps), 0))
 
     def set_max_batch(self, n):
         check(lib().tlh_session_set_max_batch(self.h, int(n)), "tlh_session_set_max_batch")

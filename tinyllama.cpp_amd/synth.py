@@ -173,7 +173,47 @@ def _kv_str(k, v):
     return _gs(k) + struct.pack("<I", 8) + _gs(v)
 
 
-def write_gguf(path, cfg, tensors, alignment=32):
+def _kv_i32(k, v):
+    return _gs(k) + struct.pack("<Ii", 5, v)
+
+
+def _gb(b):
+    return struct.pack("<Q", len(b)) + bytes(b)
+
+
+def tokenizer_kvs(tokens, model="llama", merges=None, scores=None, token_types=None, bos=None, eos=None, unk=None,
+                  pad=None, chat_template=None, vocab_size=None):
+    """The tokenizer.* metadata the reference reads (gguf_parser.cpp:240-300, model_config.cpp:199-253). `tokens`,
+    `merges`, `chat_template` are bytes (token texts need not be UTF-8)."""
+    kvs = [_kv_str("tokenizer.ggml.model", model),
+           _gs("tokenizer.ggml.tokens") + struct.pack("<IIQ", 9, 8, len(tokens)) + b"".join(_gb(t) for t in tokens)]
+    if merges is not None:
+        kvs.append(_gs("tokenizer.ggml.merges") + struct.pack("<IIQ", 9, 8, len(merges)) + b"".join(_gb(m) for m in merges))
+    if scores is not None:
+        kvs.append(_gs("tokenizer.ggml.scores") + struct.pack("<IIQ", 9, 6, len(scores)) +
+                   np.asarray(scores, np.float32).tobytes())
+    if token_types is not None:
+        kvs.append(_gs("tokenizer.ggml.token_type") + struct.pack("<IIQ", 9, 5, len(token_types)) +
+                   np.asarray(token_types, np.int32).tobytes())
+    for key, v in (("bos_token_id", bos), ("eos_token_id", eos), ("unk_token_id", unk), ("padding_token_id", pad)):
+        if v is not None:
+            kvs.append(_kv_i32("tokenizer.ggml." + key, v))
+    if chat_template is not None:
+        kvs.append(_gs("tokenizer.chat_template") + struct.pack("<I", 8) + _gb(chat_template))
+    if vocab_size is not None:
+        kvs.append(_kv_u32("tokenizer.ggml.vocab_size", vocab_size))
+    return kvs
+
+
+def write_metadata_gguf(path, kvs, architecture="llama"):
+    """A GGUF v3 file with metadata only (no tensors): what the tokenizer tests open."""
+    kvs = [_kv_str("general.architecture", architecture)] + list(kvs)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IIQQ", 0x46554747, 3, 0, len(kvs)) + b"".join(kvs))
+    return path
+
+
+def write_gguf(path, cfg, tensors, alignment=32, extra_kvs=()):
     """Write `tensors` ({name: (type, array, rows, cols)}) with the metadata keys the reference reads
     (model_config.cpp:149-221). ggml dim order: dims[0] = cols (in_features), dims[1] = rows."""
     kvs = [
@@ -189,9 +229,10 @@ def write_gguf(path, cfg, tensors, alignment=32):
         _kv_u32("llama.vocab_size", cfg["vocab"]),
         _kv_f32("llama.attention.layer_norm_rms_epsilon", cfg["eps"]),
         _kv_f32("llama.rope.freq_base", cfg["rope_theta"]),
-        _kv_u32("tokenizer.ggml.bos_token_id", 1),
-        _kv_u32("tokenizer.ggml.eos_token_id", 2),
     ]
+    if not extra_kvs:
+        kvs += [_kv_u32("tokenizer.ggml.bos_token_id", 1), _kv_u32("tokenizer.ggml.eos_token_id", 2)]
+    kvs += list(extra_kvs)
     infos, offset, order = [], 0, []
     for name, (typ, arr, rows, cols) in tensors.items():
         nbytes = arr.nbytes

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   const int SL = tl_attn_split_len(len);
   const int active = (len + SL - 1) / SL;
   if (split >= active || pos < 0 || pos >= a.max_seq) return;  // (the combine only reads splits < active)
-  const int kv_dim = a.nkv * HD;
+  const int kv_dim = a.kv_row;
+  const size_t hoff = (size_t)kvh * (size_t)a.kv_head;
   const int t0 = split * SL;
   const int t1 = len < t0 + SL ? len : t0 + SL;
   const bool owner = FUSE && split == active - 1;  // this split holds the new position, which is not in the cache yet
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
 #pragma unroll
     for (int v = 0; v < NV; ++v) qf[g][v] = *reinterpret_cast<const f32x4*>(a.q + (size_t)(head0 + g) * HD + 64 * v + 4 * ln);
 
-  const float* kbase = a.kc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
-  const float* vbase = a.vc + (size_t)t0 * kv_dim + (size_t)kvh * HD + 4 * ln;
+  const float* kbase = a.kc + (size_t)t0 * kv_dim + hoff + 4 * ln;
+  const float* vbase = a.vc + (size_t)t0 * kv_dim + hoff + 4 * ln;
   f32x4 kk[U * NV], vv[U * NV];
   unsigned valid = 0;  // bit u: slot u of the batch in flight holds a row of this split
   // slot u of a batch holds row base + (u * NW + wave) * PP + sub (rows go round the waves first, so short splits use
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
       rope2(kr[2], kr[3], tq[v][2], tq[v][3], o0, o1);
       kn[v][2] = o0; kn[v][3] = o1;
       if (sub == 0 && blockIdx.z == 0) {
-        *reinterpret_cast<f32x4*>(a.kc + (size_t)pos * kv_dim + (size_t)kvh * HD + 64 * v + 4 * ln) = kn[v];
-        *reinterpret_cast<f32x4*>(a.vc + (size_t)pos * kv_dim + (size_t)kvh * HD + 64 * v + 4 * ln) = vn[v];
+        *reinterpret_cast<f32x4*>(a.kc + (size_t)pos * kv_dim + hoff + 64 * v + 4 * ln) = kn[v];
+        *reinterpret_cast<f32x4*>(a.vc + (size_t)pos * kv_dim + hoff + 64 * v + 4 * ln) = vn[v];
       }
     }
     fold(kn, vn, sub == 0 ? 1u : 0u, std::integral_constant<int, 1>{});
@@ -468,7 +469,12 @@ int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s) {
              a.nkv, a.hd);
   TL_REQUIRE(a.ws, "attention: workspace missing");
   const int P = heads_per_workgroup(a.nh / a.nkv);
-  return a.hd == 64 ? launch_h<64>(a, P, fuse, s) : launch_h<128>(a, P, fuse, s);
+  AttnArgs b = a;
+  if (b.kv_row == 0) {
+    b.kv_row = a.nkv * a.hd;
+    b.kv_head = a.hd;
+  }
+  return a.hd == 64 ? launch_h<64>(b, P, fuse, s) : launch_h<128>(b, P, fuse, s);
 }
 
 int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s) {

@@ -184,6 +184,10 @@ struct AttnArgs {
   // != NULL: one zero-initialised counter per head group (nh / G of them; the kernel leaves them at zero). From
   // TL_ATTN_MERGE_MIN active splits on, the last workgroup of a head group merges the group's partials into record 0
   unsigned* done_cnt;
+  // K/V addressing in floats: position t of kv head h starts at t * kv_row + h * kv_head. 0 / 0 = the reference's
+  // [max_seq][nkv][hd] (kv_row = nkv * hd, kv_head = hd), filled in by the launcher
+  int kv_row;
+  long long kv_head;
   int zparts;  // = gridDim.z, set by the launcher (an explicit argument: gridDim comes from the hidden argument block
                // with a scalar load of its own)
 };

@@ -197,3 +197,30 @@ def test_batch_argument_errors(pkg):
     m.free()
     with pytest.raises(TlError):
         E.Model(dict(pkg.synth.SHAPES["tiny-gqa"]), tp_rank=0, tp_size=2).batch_init(2)  # not finalized / sharded
+
+
+def test_deferred_ksplit_reductions_are_bit_identical(pkg, monkeypatch):
+    """Skinny GEMMs split K; their partial tiles are summed by the NEXT kernel (RMSNorm split, SwiGLU split, RoPE + cache
+    write) instead of a reduction launch of their own. Same sums in the same order: logits of a batched step, a packed
+    prefill and an all-logits prefill are bit-for-bit those of TL_GEMM_DEFER=0 (one ksplit_reduce launch per GEMM)."""
+    from tinyllama_cpp_amd import engine as E
+    monkeypatch.setenv("TL_BATCH_GEMV_MAX", "0")
+    E.init(0)
+    rng = np.random.default_rng(8)
+    for shape, mix in (("tiny-tp", "q4_k_m"), ("tiny-gqa", "q6_k")):
+        cfg, tensors = pkg.synth.build_model(shape, mix, seed=5)
+        prompts = [rng.integers(0, cfg["vocab"], n).astype(np.int32) for n in [9, 3, 14, 6, 11, 2, 8, 5, 7, 10, 4, 12]]
+        long_prompt = rng.integers(0, cfg["vocab"], 100).astype(np.int32)
+        got = {}
+        for defer in ("0", "1"):
+            monkeypatch.setenv("TL_GEMM_DEFER", defer)  # read when the model's prefill workspaces are made
+            m = E.Model(cfg).load(tensors)
+            m.batch_init(12)
+            logits, ids = m.batch_prefill_packed(prompts)
+            step, nxt = m.batch_decode(list(ids), [len(p) for p in prompts], list(range(12)))
+            more = m.batch_generate_greedy(list(nxt), [len(p) + 1 for p in prompts], list(range(12)), 3)
+            _, all_logits = m.prefill(long_prompt, all_logits=True)
+            got[defer] = [np.array(x) for x in (logits, ids, step, nxt, more, all_logits)]
+            m.free()
+        for a, b in zip(got["0"], got["1"]):
+            assert a.shape == b.shape and np.array_equal(a, b), (shape, np.abs(a.astype(np.float64) - b).max())

@@ -32,10 +32,19 @@ __device__ __forceinline__ void rot2(float a, float b, float c, float s, float& 
 }
 
 // q [T][nq][hd], k [T][nkv][hd] rotated in place at pos[t]; k, v of token t written to cache row (seq[t], pos[t])
+// pq / pk / pv: S != 0 = that projection is still the partial tiles of a K-split GEMM and is summed here, in slice order
+// (what ksplit_reduce_kernel would have left in q / k / v)
+__device__ __forceinline__ float ld_parts(const float* base, const GemmParts& g, size_t o) {
+  if (!g.S) return base[o];
+  float acc = g.part[o];
+  for (int z = 1; z < g.S; ++z) acc += g.part[(size_t)z * g.n + o];
+  return acc;
+}
 __global__ void batch_rope_kv_kernel(float* __restrict__ q, float* __restrict__ k, const float* __restrict__ v,
                                      float* __restrict__ kc, float* __restrict__ vc, size_t seq_stride,
                                      const float* __restrict__ table, const int* __restrict__ pos,
-                                     const int* __restrict__ seq, int T, int nq, int nkv, int hd, int max_seq, int n_seq) {
+                                     const int* __restrict__ seq, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
+                                     GemmParts pq, GemmParts pk, GemmParts pv) {
   const int half = hd >> 1, kv_dim = nkv * hd;
   const int per_tok = (nq + nkv) * half + kv_dim;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,14 +58,16 @@ __global__ void batch_rope_kv_kernel(float* __restrict__ q, float* __restrict__ 
     const float* tp = table + 2 * (size_t)p * half;
     if (h < nq) {
       float* x = q + ((size_t)t * nq + h) * hd;
+      const size_t o = ((size_t)t * nq + h) * hd + 2 * i;
       float o0, o1;
-      rot2(x[2 * i], x[2 * i + 1], tp[2 * i], tp[2 * i + 1], o0, o1);
+      rot2(ld_parts(q, pq, o), ld_parts(q, pq, o + 1), tp[2 * i], tp[2 * i + 1], o0, o1);
       x[2 * i] = o0;
       x[2 * i + 1] = o1;
     } else {
       float* x = k + ((size_t)t * nkv + (h - nq)) * hd;
+      const size_t o = ((size_t)t * nkv + (h - nq)) * hd + 2 * i;
       float o0, o1;
-      rot2(x[2 * i], x[2 * i + 1], tp[2 * i], tp[2 * i + 1], o0, o1);
+      rot2(ld_parts(k, pk, o), ld_parts(k, pk, o + 1), tp[2 * i], tp[2 * i + 1], o0, o1);
       x[2 * i] = o0;
       x[2 * i + 1] = o1;
       float* dst = kc + row + (size_t)(h - nq) * hd;
@@ -65,7 +76,7 @@ __global__ void batch_rope_kv_kernel(float* __restrict__ q, float* __restrict__ 
     }
   } else {
     const int d = rem - (nq + nkv) * half;
-    vc[row + d] = v[(size_t)t * kv_dim + d];
+    vc[row + d] = ld_parts(v, pv, (size_t)t * kv_dim + d);
   }
 }
 
@@ -262,11 +273,15 @@ __global__ __launch_bounds__(1024) void batch_argmax_advance_kernel(const float*
 
 int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,
                             const int* pos_dev, const int* seq_dev, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
-                            hipStream_t s) {
+                            hipStream_t s, const GemmParts* pq, const GemmParts* pk, const GemmParts* pv) {
   TL_REQUIRE(q && k && v && kc && vc && table && pos_dev && seq_dev && T > 0 && hd % 2 == 0, "batch rope/kv: bad argument");
+  const GemmParts none = {nullptr, 0, 0};
+  const GemmParts gq = pq ? *pq : none, gk = pk ? *pk : none, gv = pv ? *pv : none;
+  TL_REQUIRE((!gq.S || gq.n == (size_t)T * nq * hd) && (!gk.S || gk.n == (size_t)T * nkv * hd) &&
+                 (!gv.S || gv.n == (size_t)T * nkv * hd), "batch rope/kv: pending sums of another shape");
   const size_t n = (size_t)T * ((size_t)(nq + nkv) * (hd / 2) + (size_t)nkv * hd);
   batch_rope_kv_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(q, k, v, kc, vc, seq_stride, table, pos_dev, seq_dev, T, nq,
-                                                                   nkv, hd, max_seq, n_seq);
+                                                                   nkv, hd, max_seq, n_seq, gq, gk, gv);
   TL_HIP(hipGetLastError());
   return 0;
 }

@@ -929,17 +929,42 @@ enum SplitMode { SPLIT_PLAIN = 0, SPLIT_RMSNORM = 1, SPLIT_SWIGLU = 2 };
 // whole row itself (same order in all of them). SWIGLU: the batched form of cpu_batch_processor.cpp:252-256:
 // (g / (1 + exp(-g))) * u. K is a multiple of 32.
 constexpr int SPLIT_SLICE = 2048;
-template <int MODE>
+// DEF: an input is still the partial sums of a K-split GEMM (GemmParts: the reduction that ksplit_reduce_kernel would
+// have run is done here, same order: residual + (slice 0 + slice 1 + ...)). RMSNORM: x is the residual stream, d.a its
+// pending projection; the new residual stream goes to d.xout (a different buffer: the other column slice's workgroup of
+// the same token still reads x). SWIGLU: d.a replaces x (gate), d.b replaces aux (up).
+struct SplitDefer {
+  GemmParts a, b;
+  float* xout;
+};
+__device__ __forceinline__ float parts_sum(const GemmParts& g, size_t o) {
+  float acc = g.part[o];
+  for (int z = 1; z < g.S; ++z) acc += g.part[(size_t)z * g.n + o];
+  return acc;
+}
+__device__ __forceinline__ f32x4 parts_sum4(const GemmParts& g, size_t o) {
+  f32x4 acc = *reinterpret_cast<const f32x4*>(g.part + o);
+  for (int z = 1; z < g.S; ++z) acc += *reinterpret_cast<const f32x4*>(g.part + (size_t)z * g.n + o);
+  return acc;
+}
+template <int MODE, bool DEF>
 __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x, const float* __restrict__ aux,
                                                     __bf16* __restrict__ planes, size_t plane_stride, int K, int np,
-                                                    float eps, float* __restrict__ xsum, int tpad) {
+                                                    float eps, float* __restrict__ xsum, int tpad, SplitDefer d) {
   __shared__ float red[4];
   const int t = blockIdx.x;
   const float* xt = x + (size_t)t * K;
   float nf = 1.f;
   if (MODE == SPLIT_RMSNORM) {
     float ssq = 0.f;
-    for (int i = threadIdx.x; i < K; i += 256) ssq += xt[i] * xt[i];
+    if (DEF) {
+      for (int i = threadIdx.x; i < K; i += 256) {
+        const float v = xt[i] + parts_sum(d.a, (size_t)t * K + i);
+        ssq += v * v;
+      }
+    } else {
+      for (int i = threadIdx.x; i < K; i += 256) ssq += xt[i] * xt[i];
+    }
     for (int o = 32; o >= 1; o >>= 1) ssq += __shfl_xor(ssq, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
     __syncthreads();
@@ -948,15 +973,36 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
   const int i0 = blockIdx.y * SPLIT_SLICE + threadIdx.x * 8;
   if (i0 >= K) return;
   float v[8];
-  const f32x4 lo = *reinterpret_cast<const f32x4*>(xt + i0), hi = *reinterpret_cast<const f32x4*>(xt + i0 + 4);
+  f32x4 lo, hi;
+  const size_t o0 = (size_t)t * K + i0;
+  if (DEF && MODE == SPLIT_SWIGLU && d.a.S) {
+    lo = parts_sum4(d.a, o0);
+    hi = parts_sum4(d.a, o0 + 4);
+  } else {
+    lo = *reinterpret_cast<const f32x4*>(xt + i0);
+    hi = *reinterpret_cast<const f32x4*>(xt + i0 + 4);
+    if (DEF && MODE == SPLIT_RMSNORM) {
+      lo = lo + parts_sum4(d.a, o0);
+      hi = hi + parts_sum4(d.a, o0 + 4);
+      *reinterpret_cast<f32x4*>(d.xout + o0) = lo;
+      *reinterpret_cast<f32x4*>(d.xout + o0 + 4) = hi;
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     v[e] = lo[e];
     v[4 + e] = hi[e];
   }
   if (MODE != SPLIT_PLAIN) {
-    const float* ap = MODE == SPLIT_RMSNORM ? aux + i0 : aux + (size_t)t * K + i0;
-    const f32x4 alo = *reinterpret_cast<const f32x4*>(ap), ahi = *reinterpret_cast<const f32x4*>(ap + 4);
+    f32x4 alo, ahi;
+    if (DEF && MODE == SPLIT_SWIGLU && d.b.S) {
+      alo = parts_sum4(d.b, o0);
+      ahi = parts_sum4(d.b, o0 + 4);
+    } else {
+      const float* ap = MODE == SPLIT_RMSNORM ? aux + i0 : aux + (size_t)t * K + i0;
+      alo = *reinterpret_cast<const f32x4*>(ap);
+      ahi = *reinterpret_cast<const f32x4*>(ap + 4);
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float a = e < 4 ? alo[e] : ahi[e - 4];
@@ -980,6 +1026,59 @@ __global__ __launch_bounds__(256) void split_kernel(const float* __restrict__ x,
   }
 }
 
+// RMSNORM over a residual stream whose last projection is still pending as K-split partial tiles: one workgroup of 1024
+// threads per token. Phase A sums residual + slices (vector loads, all in flight together), writes the new residual
+// stream (in place is fine: the row belongs to this workgroup) and keeps the row in LDS; phase B is split_kernel's sum of
+// squares, thread for thread (256 accumulators over columns j, j + 256, ..., butterfly per wave, four wave sums in
+// order); phase C is split_kernel's plane write with its thread -> 8 columns mapping. Bit-identical to
+// ksplit_reduce_kernel followed by split_kernel<SPLIT_RMSNORM>. K is a multiple of 32; LDS: K floats.
+__global__ __launch_bounds__(1024) void split_rmsnorm_deferred_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      __bf16* __restrict__ planes, size_t plane_stride, int K,
+                                                                      int np, float eps, float* __restrict__ xsum, int tpad,
+                                                                      GemmParts a, float* __restrict__ xout) {
+  extern __shared__ __attribute__((aligned(16))) float rowbuf[];
+  __shared__ float red[4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const size_t base = (size_t)t * K;
+  for (int i0 = tid * 4; i0 < K; i0 += 4096) {
+    const f32x4 r = *reinterpret_cast<const f32x4*>(x + base + i0) + parts_sum4(a, base + i0);
+    *reinterpret_cast<f32x4*>(xout + base + i0) = r;
+    *reinterpret_cast<f32x4*>(rowbuf + i0) = r;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    float ssq = 0.f;
+    for (int i = tid; i < K; i += 256) ssq += rowbuf[i] * rowbuf[i];
+    for (int o = 32; o >= 1; o >>= 1) ssq += __shfl_xor(ssq, o);
+    if ((tid & 63) == 0) red[tid >> 6] = ssq;
+  }
+  __syncthreads();
+  const float nf = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+  for (int i0 = tid * 8; i0 < K; i0 += 8192) {
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(rowbuf + i0), hi = *reinterpret_cast<const f32x4*>(rowbuf + i0 + 4);
+    const f32x4 alo = *reinterpret_cast<const f32x4*>(w + i0), ahi = *reinterpret_cast<const f32x4*>(w + i0 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xv = e < 4 ? lo[e] : hi[e - 4], av = e < 4 ? alo[e] : ahi[e - 4];
+      v[e] = xv * nf * av;
+    }
+    float bs = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    bs += __shfl_xor(bs, 1);
+    bs += __shfl_xor(bs, 2);
+    if ((tid & 3) == 0) xsum[(size_t)(i0 >> 5) * tpad + t] = bs;
+    for (int p = 0; p < np; ++p) {
+      bf16x8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        b[e] = (__bf16)v[e];
+        v[e] -= (float)b[e];
+      }
+      *reinterpret_cast<bf16x8*>(planes + p * plane_stride + base + i0) = b;
+    }
+  }
+}
+
 int planes_of_terms(int terms) { return terms == 1 ? 1 : terms == 3 ? 2 : 3; }
 
 // y[o] = (resid ? resid[o] : 0) + sum over the K slices, in slice order
@@ -1000,6 +1099,9 @@ static bool ksplit_enabled() {
   return on != 0;
 }
 static int gemm_num_cus() { return tl_num_cus(); }
+// set by tl_launch_gemm_q around its dispatch when the caller takes over the reduction (GemmDefer): a K-split launch then
+// leaves its partial tiles in the caller's buffer and launches no ksplit_reduce_kernel
+static thread_local GemmDefer* t_defer = nullptr;
 // the workspace of a stream's K-split GEMMs: launches of one stream are ordered, launches of different streams (q | k, v
 // and gate | up run side by side) must not share one. Eight slots; a ninth stream takes over the slot used longest
 // ago after a device-wide sync (streams of freed models leave their slots behind); -1 only if that sync fails.
@@ -1028,6 +1130,36 @@ static int ksplit_slot(hipStream_t s) {
   seen[slot] = s;
   used[slot] = tick;
   return TL_SCRATCH_GEMM_PART0 + slot;
+}
+
+// where a K-split launch of S slices puts its partial tiles: the caller's buffer when the reduction is deferred (and the
+// buffer is large enough), else the stream's workspace slot; S = 1 when neither is to be had
+static int ksplit_workspace(hipStream_t s, int T, int rows, int* S, float** part, bool* deferred) {
+  *part = nullptr;
+  *deferred = false;
+  if (*S <= 1) return 0;
+  const size_t floats = (size_t)*S * T * rows;
+  if (t_defer && t_defer->buf && t_defer->cap_floats >= floats) {
+    *part = t_defer->buf;
+    *deferred = true;
+    return 0;
+  }
+  const int slot = ksplit_slot(s);
+  if (slot < 0) {
+    *S = 1;
+    return 0;
+  }
+  void* p = nullptr;
+  TL_TRY(tl_scratch(slot, sizeof(float) * floats, &p));
+  *part = static_cast<float*>(p);
+  return 0;
+}
+static void ksplit_finish(const float* part, int S, size_t n, const float* resid, float* y, bool deferred, hipStream_t s) {
+  if (deferred) {
+    t_defer->got = {part, n, S};
+    return;
+  }
+  ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
 }
 
 template <int TYPE, int NP, int NT, int BM>
@@ -1061,21 +1193,13 @@ int launch_gemm_ws_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
     S = (nk_all + kper - 1) / kper;  // no empty slice
   }
   float* part = nullptr;
-  if (S > 1) {
-    const int slot = ksplit_slot(s);
-    if (slot < 0) S = 1;
-    else {
-      void* p = nullptr;
-      TL_TRY(tl_scratch(slot, sizeof(float) * (size_t)S * T * w.rows, &p));
-      part = static_cast<float*>(p);
-    }
-  }
+  bool deferred = false;
+  TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
   if (S == 1) {
     gemm_q_ws_kernel<TYPE, NP, NT, BM, BN><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, y, resid, T, mtiles, ntiles);
   } else {
     gemm_q_ws_kernel<TYPE, NP, NT, BM, BN><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, part, nullptr, T, mtiles, ntiles);
-    const size_t n = (size_t)T * w.rows;
-    ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
+    ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
   }
   TL_HIP(hipGetLastError());
   return 0;
@@ -1111,21 +1235,13 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
     S = (nk_all + kper - 1) / kper;
   }
   float* part = nullptr;
-  if (S > 1) {
-    const int slot = ksplit_slot(s);
-    if (slot < 0) S = 1;
-    else {
-      void* p = nullptr;
-      TL_TRY(tl_scratch(slot, sizeof(float) * (size_t)S * T * w.rows, &p));
-      part = static_cast<float*>(p);
-    }
-  }
+  bool deferred = false;
+  TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
   if (S == 1) {
     gemm_qi_ws_kernel<TYPE, NPX, BN, BM><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, xsum, tpad, y, resid, T, mtiles, ntiles);
   } else {
     gemm_qi_ws_kernel<TYPE, NPX, BN, BM><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, xsum, tpad, part, nullptr, T, mtiles, ntiles);
-    const size_t n = (size_t)T * w.rows;
-    ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
+    ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
   }
   TL_HIP(hipGetLastError());
   return 0;
@@ -1161,21 +1277,13 @@ int launch_gemm_qd_inst(const QW& w, const __bf16* xp, size_t ps, float* y, cons
   const int tpad = (int)tl_gemm_padded_tokens(T);
   const int tiles = mtiles * ntiles;
   float* part = nullptr;
-  if (S > 1) {
-    const int slot = ksplit_slot(s);
-    if (slot < 0) S = 1;
-    else {
-      void* p = nullptr;
-      TL_TRY(tl_scratch(slot, sizeof(float) * (size_t)S * T * w.rows, &p));
-      part = static_cast<float*>(p);
-    }
-  }
+  bool deferred = false;
+  TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
   if (S == 1) {
     gemm_qd_kernel<TYPE, NPX, NI, NW><<<dim3(tiles), dim3(64 * NW), lds, s>>>(w, xp, ps, xsum, tpad, y, resid, T, mtiles, ntiles);
   } else {
     gemm_qd_kernel<TYPE, NPX, NI, NW><<<dim3(tiles, S), dim3(64 * NW), lds, s>>>(w, xp, ps, xsum, tpad, part, nullptr, T, mtiles, ntiles);
-    const size_t n = (size_t)T * w.rows;
-    ksplit_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(part, S, n, resid, y);
+    ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
   }
   TL_HIP(hipGetLastError());
   return 0;
@@ -1271,7 +1379,7 @@ size_t tl_gemm_padded_tokens(int T) { return (size_t)((T + GB_N - 1) / GB_N) * G
 size_t tl_gemm_planes_bytes(size_t plane_stride) { return 3 * plane_stride * sizeof(__bf16) + plane_stride / 32 * sizeof(float); }
 
 int tl_launch_split(int mode, const float* x, const float* aux, void* planes, size_t plane_stride, int T, int K,
-                    int terms, float eps, hipStream_t s) {
+                    int terms, float eps, hipStream_t s, const GemmParts* pa, const GemmParts* pb, float* xout) {
   if (T == 0) return 0;
   const int np = planes_of_terms(terms);
   __bf16* pl = static_cast<__bf16*>(planes);
@@ -1279,21 +1387,57 @@ int tl_launch_split(int mode, const float* x, const float* aux, void* planes, si
   const dim3 grid(T, (K + SPLIT_SLICE - 1) / SPLIT_SLICE);
   float* xsum = reinterpret_cast<float*>(pl + 3 * plane_stride);  // [K / 32][padded tokens], behind the three planes
   const int tpad = (int)tl_gemm_padded_tokens(T);
-  if (mode == SPLIT_RMSNORM) split_kernel<SPLIT_RMSNORM><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad);
-  else if (mode == SPLIT_SWIGLU) split_kernel<SPLIT_SWIGLU><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad);
-  else split_kernel<SPLIT_PLAIN><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad);
+  SplitDefer d = {};
+  if (pa && pa->S) d.a = *pa;
+  if (pb && pb->S) d.b = *pb;
+  d.xout = xout;
+  const bool def = d.a.S || d.b.S;
+  if (def) {
+    const size_t n = (size_t)T * K;
+    TL_REQUIRE(mode != SPLIT_PLAIN && (!d.a.S || d.a.n == n) && (!d.b.S || d.b.n == n), "tl_launch_split: deferred sums of another shape");
+    TL_REQUIRE(mode != SPLIT_RMSNORM || (d.a.S && !d.b.S && xout && xout != x), "tl_launch_split: RMSNorm over a pending projection needs a second residual buffer");
+  }
+  if (mode == SPLIT_RMSNORM) {
+    if (def && K % 32 == 0 && (size_t)K * sizeof(float) <= 48 * 1024)
+      split_rmsnorm_deferred_kernel<<<T, 1024, (size_t)K * sizeof(float), s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad, d.a, xout);
+    else if (def) split_kernel<SPLIT_RMSNORM, true><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad, d);
+    else split_kernel<SPLIT_RMSNORM, false><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad, d);
+  } else if (mode == SPLIT_SWIGLU) {
+    if (def) split_kernel<SPLIT_SWIGLU, true><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad, d);
+    else split_kernel<SPLIT_SWIGLU, false><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad, d);
+  } else {
+    split_kernel<SPLIT_PLAIN, false><<<grid, 256, 0, s>>>(x, aux, pl, plane_stride, K, np, eps, xsum, tpad, d);
+  }
   TL_HIP(hipGetLastError());
   return 0;
 }
 
 // planes: [planes_of_terms(terms)][plane_stride] bf16 with plane_stride >= tl_gemm_padded_tokens(T) * w.cols
+// defer != NULL: if the launch splits K and defer->buf holds the partial tiles, no reduction is launched and defer->got
+// describes them (the consumer adds `resid` itself); otherwise defer->got.S = 0 and y is complete as usual
+static int launch_gemm_dispatch(const QW& w, const __bf16* xp, size_t plane_stride, float* y, const float* resid, int T,
+                                int terms, hipStream_t s);
 int tl_launch_gemm_q(const QW& w, const void* planes, size_t plane_stride, float* y, const float* resid, int T,
-                     int terms, hipStream_t s) {
+                     int terms, hipStream_t s, GemmDefer* defer) {
   TL_REQUIRE(terms == 1 || terms == 3 || terms == 6, "tl_launch_gemm_q: terms must be 1, 3 or 6 (got %d)", terms);
   TL_REQUIRE(w.cols % GB_K == 0 && w.rows > 0, "tl_launch_gemm_q: bad weight shape %d x %d", w.rows, w.cols);
   TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w.cols, "tl_launch_gemm_q: activation planes too small");
+  if (defer) defer->got = {nullptr, 0, 0};
   if (T == 0) return 0;
   const __bf16* xp = static_cast<const __bf16*>(planes);
+  t_defer = defer;
+  const int rc = launch_gemm_dispatch(w, xp, plane_stride, y, resid, T, terms, s);
+  t_defer = nullptr;
+  return rc;
+}
+int tl_launch_ksplit_reduce(const GemmParts& g, const float* resid, float* y, hipStream_t s) {
+  if (!g.S) return 0;
+  ksplit_reduce_kernel<<<(unsigned)((g.n + 255) / 256), 256, 0, s>>>(g.part, g.S, g.n, resid, y);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+static int launch_gemm_dispatch(const QW& w, const __bf16* xp, size_t plane_stride, float* y, const float* resid, int T,
+                                int terms, hipStream_t s) {
   switch (w.type) {
     case TL_Q4_K: return launch_gemm_typed<TL_Q4_K>(w, xp, plane_stride, y, resid, T, terms, s);
     case TL_Q6_K: return launch_gemm_typed<TL_Q6_K>(w, xp, plane_stride, y, resid, T, terms, s);

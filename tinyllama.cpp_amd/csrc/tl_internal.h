@@ -202,10 +202,28 @@ int tl_gemm_default_terms();
 size_t tl_gemm_padded_tokens(int T);
 size_t tl_gemm_planes_bytes(size_t plane_stride);  // three bf16 planes + FP32 block sums
 // mode 0: planes = split(x[T][K]); 1: split(rmsnorm_batch(x, aux = weight[K], eps)); 2: split(swiglu(x, aux[T][K]))
+// partial sums a K-split GEMM left for its consumer: value[o] = part[o] + part[n + o] + ... (S slices, in that order);
+// S == 0: nothing pending
+struct GemmParts {
+  const float* part;
+  size_t n;
+  int S;
+};
+// handed to tl_launch_gemm_q by a caller whose next kernel does the reduction itself: buf / cap_floats in, got out
+struct GemmDefer {
+  float* buf;
+  size_t cap_floats;
+  GemmParts got;
+};
+// pa / pb: pending sums (RMSNORM: pa = the projection to add to the residual stream x, the sum goes to xout != x;
+// SWIGLU: pa replaces x, pb replaces aux)
 int tl_launch_split(int mode, const float* x, const float* aux, void* planes, size_t plane_stride, int T, int K,
-                    int terms, float eps, hipStream_t s);
+                    int terms, float eps, hipStream_t s, const GemmParts* pa = nullptr, const GemmParts* pb = nullptr,
+                    float* xout = nullptr);
 int tl_launch_gemm_q(const QW& w, const void* planes, size_t plane_stride, float* y, const float* resid, int T,
-                     int terms, hipStream_t s);
+                     int terms, hipStream_t s, GemmDefer* defer = nullptr);
+// y = (resid ? resid : 0) + the pending sums (what the GEMM launch would have run itself)
+int tl_launch_ksplit_reduce(const GemmParts& g, const float* resid, float* y, hipStream_t s);
 
 // causal prefill attention on the FP32 matrix instruction (tl_prefill.hip)
 bool tl_attn_prefill_mfma_supported(int nh, int nkv, int hd);
@@ -247,7 +265,8 @@ void tl_peer_destroy(TlPeer* p);
 // ---- tl_batch.hip: position-dependent kernels of the multi-sequence decode step (sequence-major KV cache) ------------
 int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,
                             const int* pos_dev, const int* seq_dev, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
-                            hipStream_t s);
+                            hipStream_t s, const GemmParts* pq = nullptr, const GemmParts* pk = nullptr,
+                            const GemmParts* pv = nullptr);
 bool tl_batch_attn_supported(int nh, int nkv, int hd);
 int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_t seq_stride, float* out, const int* pos_dev,
                          const int* seq_dev, int T, int nh, int nkv, int hd, int max_seq, int n_seq, float scale,

@@ -88,6 +88,13 @@ struct tl_model {
     int cap = 0;               // tokens per chunk the buffers hold
     float *xb = nullptr, *qb = nullptr, *kb = nullptr, *vb = nullptr, *ab = nullptr, *gb = nullptr, *ub = nullptr;
     float* xpart = nullptr;    // tp > 1: this rank's partial of attn_output / ffn_down for the chunk, all-reduced into xb
+    // K-split GEMMs leave their partial tiles for the next kernel to sum (no reduction launch, tl_gemm.hip GemmDefer):
+    // part[0] q / attn_output / gate / ffn_down, part[1] k / up, part[2] v; `pend` = the projection not yet added to xb
+    // (folded into the next RMSNorm split, which writes the new residual stream to xb2; the two then swap)
+    float* xb2 = nullptr;
+    float* part[3] = {nullptr, nullptr, nullptr};
+    size_t part_cap = 0;
+    GemmParts pend = {nullptr, 0, 0};
     void* planes = nullptr;    // bf16 [3][plane_stride]
     size_t plane_stride = 0;
     float* logits_all = nullptr;  // [cap][vocab], only when all logits were asked for
@@ -205,7 +212,8 @@ extern "C" int tl_model_free(tl_model* m) {
   hipFree(m->cand_i);
   hipFree(m->attn_ws);
   hipFree(m->xn);
-  float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all, m->pf.xpart};
+  float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all, m->pf.xpart,
+                    m->pf.xb2, m->pf.part[0], m->pf.part[1], m->pf.part[2]};
   for (float* b : pbufs) hipFree(b);
   hipFree(m->pf.planes);
   hipFree(m->pf.toks);
@@ -1026,6 +1034,16 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
     p.plane_stride = tl_gemm_padded_tokens(cap) * kmax;
     TL_HIP(hipMalloc(&p.xb, sizeof(float) * cap * H));
     if (m->tp > 1) TL_HIP(hipMalloc(&p.xpart, sizeof(float) * cap * H));
+    const char* dz = getenv("TL_GEMM_DEFER");  // 0: every K-split GEMM runs its own reduction launch (A/B runs)
+    if (m->tp == 1 && !(dz && atoi(dz) == 0)) {
+      // a split launch has fewer than 4 * CUs (slice, tile) pairs of at most 128 x 128 outputs
+      const size_t rows_max = kmax > (size_t)c.vocab_size ? kmax : (size_t)c.vocab_size;
+      size_t floats = (size_t)4 * tl_num_cus() * 128 * 128;
+      if (floats > (size_t)8 * cap * rows_max) floats = (size_t)8 * cap * rows_max;
+      TL_HIP(hipMalloc(&p.xb2, sizeof(float) * cap * H));
+      for (int i = 0; i < 3; ++i) TL_HIP(hipMalloc(&p.part[i], sizeof(float) * floats));
+      p.part_cap = floats;
+    }
     TL_HIP(hipMalloc(&p.qb, sizeof(float) * cap * (size_t)m->qd_l));
     TL_HIP(hipMalloc(&p.kb, sizeof(float) * cap * (size_t)m->kv_dim));
     TL_HIP(hipMalloc(&p.vb, sizeof(float) * cap * (size_t)m->kv_dim));
@@ -1050,6 +1068,37 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
 static int prefill_embed(tl_model* m, const int* toks_dev, int T, hipStream_t s) {
   return tl_launch_dequant_gather(m->tok, toks_dev, T, m->pf.xb, s);
 }
+// RMSNorm of the residual stream -> activation planes; a projection still pending as K-split partials is added on the way
+static int split_residual(tl_model* m, const float* norm_w, int T, hipStream_t s) {
+  tl_model::Prefill& p = m->pf;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  if (!p.pend.S) return tl_launch_split(1, p.xb, norm_w, p.planes, p.plane_stride, T, m->cfg.hidden_size, terms, m->cfg.rms_norm_eps, s);
+  TL_TRY(tl_launch_split(1, p.xb, norm_w, p.planes, p.plane_stride, T, m->cfg.hidden_size, terms, m->cfg.rms_norm_eps, s,
+                         &p.pend, nullptr, p.xb2));
+  std::swap(p.xb, p.xb2);
+  p.pend = {nullptr, 0, 0};
+  return 0;
+}
+// the residual stream complete in pf.xb (after the last layer, or wherever something other than a split reads it)
+static int flush_residual(tl_model* m, hipStream_t s) {
+  tl_model::Prefill& p = m->pf;
+  if (!p.pend.S) return 0;
+  TL_TRY(tl_launch_ksplit_reduce(p.pend, p.xb, p.xb, s));
+  p.pend = {nullptr, 0, 0};
+  return 0;
+}
+// a row-split projection (attn_output, ffn_down) added to the residual stream: now, or pending
+static int project_residual(tl_model* m, const tl_qweight* w, int T, hipStream_t s) {
+  tl_model::Prefill& p = m->pf;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  if (m->tp > 1 || !p.part_cap)
+    return tl_launch_gemm_q(qw_view(w), p.planes, p.plane_stride, m->tp > 1 ? p.xpart : p.xb, m->rank == 0 ? p.xb : nullptr, T,
+                            terms, s);
+  GemmDefer d = {p.part[0], p.part_cap, {nullptr, 0, 0}};
+  TL_TRY(tl_launch_gemm_q(qw_view(w), p.planes, p.plane_stride, p.xb, p.xb, T, terms, s, &d));
+  p.pend = d.got;
+  return 0;
+}
 static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream_t s) {
   const tl_model_config& c = m->cfg;
   tl_model::Prefill& p = m->pf;
@@ -1058,7 +1107,8 @@ static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream
   const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
   const size_t ps = p.plane_stride;
   const float scale = 1.0f / sqrtf((float)hd);
-  TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+  (void)H;
+  TL_TRY(split_residual(m, L.attn_norm, T, s));
   TL_HIP(hipEventRecord(p.fork, s));
   TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
   TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
@@ -1072,8 +1122,7 @@ static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream
   TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
                                     m->nkv_l, hd, scale, s));
   TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
-  return tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, m->tp > 1 ? p.xpart : p.xb,
-                          m->rank == 0 ? p.xb : nullptr, T, terms, s);
+  return project_residual(m, L.q[TL_T_ATTN_OUTPUT], T, s);
 }
 static int prefill_mlp_half(tl_model* m, int l, int T, hipStream_t s) {
   const tl_model_config& c = m->cfg;
@@ -1081,16 +1130,18 @@ static int prefill_mlp_half(tl_model* m, int l, int T, hipStream_t s) {
   LayerW& L = m->layers[l];
   const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
   const size_t ps = p.plane_stride;
-  TL_TRY(tl_launch_split(1, p.xb, L.ffn_norm, p.planes, ps, T, c.hidden_size, terms, c.rms_norm_eps, s));
+  (void)c;
+  TL_TRY(split_residual(m, L.ffn_norm, T, s));
   TL_HIP(hipEventRecord(p.fork, s));
   TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, p.side));
+  GemmDefer dg = {p.part[0], p.part_cap, {nullptr, 0, 0}}, du = {p.part[1], p.part_cap, {nullptr, 0, 0}};
+  const bool defer = p.part_cap != 0;
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s, defer ? &dg : nullptr));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, p.side, defer ? &du : nullptr));
   TL_HIP(hipEventRecord(p.join, p.side));
   TL_HIP(hipStreamWaitEvent(s, p.join, 0));
-  TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s));
-  return tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_DOWN]), p.planes, ps, m->tp > 1 ? p.xpart : p.xb,
-                          m->rank == 0 ? p.xb : nullptr, T, terms, s);
+  TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s, &dg.got, &du.got));
+  return project_residual(m, L.q[TL_T_FFN_DOWN], T, s);
 }
 static int prefill_all_reduce(tl_model* m, int T, hipStream_t s) {
   if (m->tp == 1) return 0;
@@ -1141,6 +1192,7 @@ static int prefill_batched(tl_model* m, const int* tokens_host, int num_tokens, 
       TL_TRY(prefill_mlp_half(m, l, T, s));
       TL_TRY(prefill_all_reduce(m, T, s));
     }
+    TL_TRY(flush_residual(m, s));
     if (all_logits_host) {  // final norm + lm_head for every token of the chunk (forward_cpu_logits_batch, model.cpp:1094-1156)
       TL_TRY(tl_launch_split(1, p.xb, m->out_norm, p.planes, p.plane_stride, T, (int)H, terms, c.rms_norm_eps, s));
       TL_TRY(tl_launch_gemm_q(qw_view(m->out), p.planes, p.plane_stride, p.logits_all, nullptr, T, terms, s));
@@ -1247,20 +1299,24 @@ static int batch_attn_half(tl_model* m, int l, int T, hipStream_t s) {
   const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
   const size_t ps = p.plane_stride;
   const float scale = 1.0f / sqrtf((float)hd);
-  TL_TRY(tl_launch_split(1, p.xb, L.attn_norm, p.planes, ps, T, H, terms, c.rms_norm_eps, s));
+  (void)H;
+  TL_TRY(split_residual(m, L.attn_norm, T, s));
   TL_HIP(hipEventRecord(p.fork, s));
   TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
+  GemmDefer dq = {p.part[0], p.part_cap, {nullptr, 0, 0}}, dk = {p.part[1], p.part_cap, {nullptr, 0, 0}},
+            dv = {p.part[2], p.part_cap, {nullptr, 0, 0}};
+  const bool defer = p.part_cap != 0;
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s, defer ? &dq : nullptr));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side, defer ? &dk : nullptr));
+  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side, defer ? &dv : nullptr));
   TL_HIP(hipEventRecord(p.join, p.side));
   TL_HIP(hipStreamWaitEvent(s, p.join, 0));
   TL_TRY(tl_launch_batch_rope_kv(p.qb, p.kb, p.vb, m->bkc(l), m->bvc(l), m->kv_layer_elems, m->rope, m->bt.pos, m->bt.seq, T,
-                                 m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s));
+                                 m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s, &dq.got, &dk.got, &dv.got));
   TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
                               m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s));
   TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
-  return tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_OUTPUT]), p.planes, ps, p.xb, p.xb, T, terms, s);
+  return project_residual(m, L.q[TL_T_ATTN_OUTPUT], T, s);
 }
 
 // The same step for a FEW sequences (T <= batch_gemv_max, default 8): the projections as multi-vector GEMVs
@@ -1358,7 +1414,7 @@ static int batch_layers(tl_model* m, int T, hipStream_t s) {
     TL_TRY(batch_attn_half(m, l, T, s));
     TL_TRY(prefill_mlp_half(m, l, T, s));
   }
-  return 0;
+  return flush_residual(m, s);
 }
 // final RMSNorm + lm_head of R hidden rows -> pf.logits_all [R][vocab]
 static int batch_head(tl_model* m, const float* hidden, int R, hipStream_t s) {

@@ -202,7 +202,8 @@ def test_batch_argument_errors(pkg):
 def test_deferred_ksplit_reductions_are_bit_identical(pkg, monkeypatch):
     """Skinny GEMMs split K; their partial tiles are summed by the NEXT kernel (RMSNorm split, SwiGLU split, RoPE + cache
     write) instead of a reduction launch of their own. Same sums in the same order: logits of a batched step, a packed
-    prefill and an all-logits prefill are bit-for-bit those of TL_GEMM_DEFER=0 (one ksplit_reduce launch per GEMM)."""
+    prefill and an all-logits prefill are bit-for-bit those of TL_GEMM_DEFER=0 (one ksplit_reduce launch per GEMM), with
+    and without q | k | v and gate | up merged into one launch each."""
     from tinyllama_cpp_amd import engine as E
     monkeypatch.setenv("TL_BATCH_GEMV_MAX", "0")
     E.init(0)
@@ -212,15 +213,17 @@ def test_deferred_ksplit_reductions_are_bit_identical(pkg, monkeypatch):
         prompts = [rng.integers(0, cfg["vocab"], n).astype(np.int32) for n in [9, 3, 14, 6, 11, 2, 8, 5, 7, 10, 4, 12]]
         long_prompt = rng.integers(0, cfg["vocab"], 100).astype(np.int32)
         got = {}
-        for defer in ("0", "1"):
+        for defer, merge in (("0", "1"), ("1", "0"), ("1", "1")):
             monkeypatch.setenv("TL_GEMM_DEFER", defer)  # read when the model's prefill workspaces are made
+            monkeypatch.setenv("TL_GEMM_MERGE", merge)  # q | k | v and gate | up in one launch each (needs DEFER)
             m = E.Model(cfg).load(tensors)
             m.batch_init(12)
             logits, ids = m.batch_prefill_packed(prompts)
             step, nxt = m.batch_decode(list(ids), [len(p) for p in prompts], list(range(12)))
             more = m.batch_generate_greedy(list(nxt), [len(p) + 1 for p in prompts], list(range(12)), 3)
             _, all_logits = m.prefill(long_prompt, all_logits=True)
-            got[defer] = [np.array(x) for x in (logits, ids, step, nxt, more, all_logits)]
+            got[defer + merge] = [np.array(x) for x in (logits, ids, step, nxt, more, all_logits)]
             m.free()
-        for a, b in zip(got["0"], got["1"]):
-            assert a.shape == b.shape and np.array_equal(a, b), (shape, np.abs(a.astype(np.float64) - b).max())
+        for other in ("10", "11"):
+            for a, b in zip(got["01"], got[other]):
+                assert a.shape == b.shape and np.array_equal(a, b), (shape, other, np.abs(a.astype(np.float64) - b).max())

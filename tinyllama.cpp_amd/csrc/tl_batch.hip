@@ -44,13 +44,13 @@ __global__ void batch_rope_kv_kernel(float* __restrict__ q, float* __restrict__ 
                                      float* __restrict__ kc, float* __restrict__ vc, size_t seq_stride,
                                      const float* __restrict__ table, const int* __restrict__ pos,
                                      const int* __restrict__ seq, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
-                                     GemmParts pq, GemmParts pk, GemmParts pv) {
+                                     GemmParts pq, GemmParts pk, GemmParts pv, int start_pos) {
   const int half = hd >> 1, kv_dim = nkv * hd;
   const int per_tok = (nq + nkv) * half + kv_dim;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (size_t)T * per_tok) return;
   const int t = (int)(gid / per_tok), rem = (int)(gid % per_tok);
-  const int p = pos[t], sq = seq[t];
+  const int p = pos ? pos[t] : start_pos + t, sq = seq ? seq[t] : 0;  // (no arrays: one sequence at consecutive positions)
   if (p < 0 || p >= max_seq || sq < 0 || sq >= n_seq) return;  // (validated on the host; never writes out of range)
   const size_t row = (size_t)sq * seq_stride + (size_t)p * kv_dim;
   if (rem < (nq + nkv) * half) {
@@ -273,15 +273,16 @@ __global__ __launch_bounds__(1024) void batch_argmax_advance_kernel(const float*
 
 int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,
                             const int* pos_dev, const int* seq_dev, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
-                            hipStream_t s, const GemmParts* pq, const GemmParts* pk, const GemmParts* pv) {
-  TL_REQUIRE(q && k && v && kc && vc && table && pos_dev && seq_dev && T > 0 && hd % 2 == 0, "batch rope/kv: bad argument");
+                            hipStream_t s, const GemmParts* pq, const GemmParts* pk, const GemmParts* pv, int start_pos) {
+  TL_REQUIRE(q && k && v && kc && vc && table && ((pos_dev && seq_dev) || (!pos_dev && !seq_dev && start_pos >= 0)) && T > 0 &&
+                 hd % 2 == 0, "batch rope/kv: bad argument");
   const GemmParts none = {nullptr, 0, 0};
   const GemmParts gq = pq ? *pq : none, gk = pk ? *pk : none, gv = pv ? *pv : none;
   TL_REQUIRE((!gq.S || gq.n == (size_t)T * nq * hd) && (!gk.S || gk.n == (size_t)T * nkv * hd) &&
                  (!gv.S || gv.n == (size_t)T * nkv * hd), "batch rope/kv: pending sums of another shape");
   const size_t n = (size_t)T * ((size_t)(nq + nkv) * (hd / 2) + (size_t)nkv * hd);
   batch_rope_kv_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(q, k, v, kc, vc, seq_stride, table, pos_dev, seq_dev, T, nq,
-                                                                   nkv, hd, max_seq, n_seq, gq, gk, gv);
+                                                                   nkv, hd, max_seq, n_seq, gq, gk, gv, start_pos);
   TL_HIP(hipGetLastError());
   return 0;
 }

@@ -711,9 +711,17 @@ constexpr int QD_SETS = TL_QD_SETS;  // weight register sets = 64-column steps a
 __device__ __forceinline__ u32x2 half_swap(unsigned a, unsigned b) {  // -> {[a.lo | b.lo], [a.hi | b.hi]} (32-lane halves)
   return __builtin_amdgcn_permlane32_swap(a, b, false, false);
 }
-template <int TYPE, int NPX, int NI, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_qd_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
-                                                          const float* __restrict__ xsum, int tpad, float* __restrict__ y,
+// NSEG = 3: up to three matrices that share the activation planes (q | k | v, gate | up: same K, same format) in ONE
+// launch; the row tiles of the matrices follow each other in the tile index, every tile computes exactly what it would
+// in a launch of its own (QDSegs::mt_end = cumulative row-tile counts; no residual in that form).
+struct QDSegs {
+  QW w[3];
+  float* y[3];
+  int mt_end[3];
+};
+template <int TYPE, int NPX, int NI, int NW, int NSEG>
+__global__ __launch_bounds__(64 * NW) void gemm_qd_kernel(QDSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
+                                                          const float* __restrict__ xsum, int tpad,
                                                           const float* __restrict__ resid, int T, int mtiles, int ntiles) {
   constexpr int BN = 32 * NI, NT = 64 * NW, BMD = 32 * NW;
   constexpr bool PER16 = TYPE == TL_Q6_K;
@@ -722,9 +730,16 @@ __global__ __launch_bounds__(64 * NW) void gemm_qd_kernel(QW w, const __bf16* __
   constexpr int XR = (XPIECES + NT - 1) / NT;      // pieces per thread
   constexpr size_t BUF_BYTES = (size_t)2 * NPX * XPL * sizeof(__bf16) + 2 * BN * sizeof(float);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int M = w.rows, K = w.cols;
   const int tile = blockIdx.x;
-  const int nt = tile / mtiles, mt = tile - nt * mtiles;
+  const int nt = tile / mtiles;
+  int mt = tile - nt * mtiles, seg = 0;
+  if (NSEG > 1) {
+    seg = (mt >= segs.mt_end[0]) + (mt >= segs.mt_end[1]);
+    if (seg) mt -= segs.mt_end[seg - 1];
+  }
+  const QW w = segs.w[seg];
+  float* __restrict__ y = segs.y[seg];
+  const int M = w.rows, K = w.cols;
   const int m0 = mt * BMD, n0 = nt * BN;
   const int ns_all = K / 64, sper = (ns_all + (int)gridDim.y - 1) / (int)gridDim.y;
   const int sbase = (int)blockIdx.y * sper;
@@ -1279,18 +1294,22 @@ int launch_gemm_qd_inst(const QW& w, const __bf16* xp, size_t ps, float* y, cons
   float* part = nullptr;
   bool deferred = false;
   TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
+  QDSegs g = {};
+  g.w[0] = w;
+  g.y[0] = S == 1 ? y : part;
   if (S == 1) {
-    gemm_qd_kernel<TYPE, NPX, NI, NW><<<dim3(tiles), dim3(64 * NW), lds, s>>>(w, xp, ps, xsum, tpad, y, resid, T, mtiles, ntiles);
+    gemm_qd_kernel<TYPE, NPX, NI, NW, 1><<<dim3(tiles), dim3(64 * NW), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, mtiles, ntiles);
   } else {
-    gemm_qd_kernel<TYPE, NPX, NI, NW><<<dim3(tiles, S), dim3(64 * NW), lds, s>>>(w, xp, ps, xsum, tpad, part, nullptr, T, mtiles, ntiles);
+    gemm_qd_kernel<TYPE, NPX, NI, NW, 1><<<dim3(tiles, S), dim3(64 * NW), lds, s>>>(g, xp, ps, xsum, tpad, nullptr, T, mtiles, ntiles);
     ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
   }
   TL_HIP(hipGetLastError());
   return 0;
 }
-template <int TYPE, int NPX, int NI>
-int launch_gemm_qd_ni(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
-  const int ntiles = (T + 32 * NI - 1) / (32 * NI), nk_all = w.cols / 64, want = 2 * gemm_num_cus();
+// waves per workgroup and K slices of the direct kernel for one matrix: eight waves (256 rows) share a staged activation
+// tile when that still fills the chip, else four
+static void qd_shape(int rows, int cols, int ntiles, int* NW, int* S) {
+  const int nk_all = cols / 64, want = 2 * gemm_num_cus();
   auto slices = [&](int tiles) {
     int S = 1;
     if (ksplit_enabled() && tiles < want) {
@@ -1303,11 +1322,42 @@ int launch_gemm_qd_ni(const QW& w, const __bf16* xp, size_t ps, float* y, const 
     }
     return S;
   };
-  // eight waves (256 rows) share a staged activation tile when that still fills the chip, else four
-  const int tiles8 = (w.rows + 255) / 256 * ntiles, tiles4 = (w.rows + 127) / 128 * ntiles;
+  const int tiles8 = (rows + 255) / 256 * ntiles, tiles4 = (rows + 127) / 128 * ntiles;
   const int S8 = slices(tiles8);
-  if (tiles8 * S8 >= want) return launch_gemm_qd_inst<TYPE, NPX, NI, 8>(w, xp, ps, y, resid, T, S8, s);
-  return launch_gemm_qd_inst<TYPE, NPX, NI, 4>(w, xp, ps, y, resid, T, slices(tiles4), s);
+  if (tiles8 * S8 >= want) {
+    *NW = 8;
+    *S = S8;
+  } else {
+    *NW = 4;
+    *S = slices(tiles4);
+  }
+}
+template <int TYPE, int NPX, int NI>
+int launch_gemm_qd_ni(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  int NW = 4, S = 1;
+  qd_shape(w.rows, w.cols, (T + 32 * NI - 1) / (32 * NI), &NW, &S);
+  if (NW == 8) return launch_gemm_qd_inst<TYPE, NPX, NI, 8>(w, xp, ps, y, resid, T, S, s);
+  return launch_gemm_qd_inst<TYPE, NPX, NI, 4>(w, xp, ps, y, resid, T, S, s);
+}
+// n matrices in one launch (gemm_qd_kernel NSEG = 3), four waves per workgroup; S slices for every one of them
+template <int TYPE, int NPX, int NI>
+int launch_gemm_qd_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, int T, int S, hipStream_t s) {
+  constexpr int NW = 4, BN = 32 * NI, BMD = 32 * NW;
+  constexpr size_t lds = 2 * ((size_t)2 * NPX * BN * LROW * sizeof(__bf16) + 2 * BN * sizeof(float));
+  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
+  const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + BN - 1) / BN;
+  QDSegs g = {};
+  int mt = 0;
+  for (int i = 0; i < 3; ++i) {
+    const int k = i < n ? i : n - 1;  // (unused slots repeat the last matrix; their tile range is empty)
+    g.w[i] = w[k];
+    g.y[i] = out[k];
+    if (i < n) mt += (w[i].rows + BMD - 1) / BMD;
+    g.mt_end[i] = mt;
+  }
+  gemm_qd_kernel<TYPE, NPX, NI, NW, 3><<<dim3(mt * ntiles, S), dim3(64 * NW), lds, s>>>(g, xp, ps, xsum, tpad, nullptr, T, mt, ntiles);
+  TL_HIP(hipGetLastError());
+  return 0;
 }
 template <int TYPE>
 int launch_gemm_qd(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms, hipStream_t s) {
@@ -1445,6 +1495,61 @@ static int launch_gemm_dispatch(const QW& w, const __bf16* xp, size_t plane_stri
     case TL_Q8_K: return launch_gemm_typed<TL_Q8_K>(w, xp, plane_stride, y, resid, T, terms, s);
     default: TL_REQUIRE(false, "tl_launch_gemm_q: weight type %d has no MFMA path", w.type);
   }
+  return 0;
+}
+
+// Up to three matrices over the same activation planes (q | k | v, gate | up) in one launch of the direct small-token
+// kernel. Taken only when that changes no bit: all matrices of one format and width, the token count on the direct
+// route, and the same number of K slices for each as its own launch would use (then every tile computes what it would
+// alone). Outputs: with one slice y[i] directly; with more, the partial tiles go to defer[i] (required) for the consumer
+// to sum. *merged = false: nothing was launched, the caller runs the matrices one by one.
+int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_stride, float* const* y, int T, int terms,
+                           hipStream_t s, GemmDefer* const* defer, bool* merged) {
+  *merged = false;
+  const char* e = getenv("TL_GEMM_MERGE");  // 0: one launch per matrix (A/B runs; read at every call)
+  const bool on = e ? atoi(e) != 0 : true;
+  const char* q = getenv("TL_GEMM_INT");
+  if (!on || (q && atoi(q) == 0) || n < 2 || n > 3 || T <= 0 || terms == 1 || T > gemm_direct_max()) return 0;
+  const int NI = T > 32 ? 2 : 1, ntiles = (T + 32 * NI - 1) / (32 * NI);
+  int S = 0;
+  for (int i = 0; i < n; ++i) {
+    if (w[i].type != w[0].type || w[i].cols != w[0].cols || w[i].cols % 64 != 0 || w[i].rows <= 0) return 0;
+    int nw = 0, si = 1;
+    qd_shape(w[i].rows, w[i].cols, ntiles, &nw, &si);
+    if (i && si != S) return 0;
+    S = si;
+  }
+  TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w[0].cols, "tl_launch_gemm_q_multi: activation planes too small");
+  float* out[3] = {nullptr, nullptr, nullptr};
+  for (int i = 0; i < n; ++i) {
+    if (S == 1) {
+      out[i] = y[i];
+      if (defer && defer[i]) defer[i]->got = {nullptr, 0, 0};
+    } else {
+      const size_t floats = (size_t)S * T * w[i].rows;
+      if (!defer || !defer[i] || !defer[i]->buf || defer[i]->cap_floats < floats) return 0;
+      out[i] = defer[i]->buf;
+    }
+  }
+  const __bf16* xp = static_cast<const __bf16*>(planes);
+  int rc = 0;
+#define TL_QD_MULTI(TYPE)                                                                                           \
+  rc = terms == 3 ? (NI == 2 ? launch_gemm_qd_multi<TYPE, 2, 2>(w, n, xp, plane_stride, out, T, S, s)               \
+                             : launch_gemm_qd_multi<TYPE, 2, 1>(w, n, xp, plane_stride, out, T, S, s))              \
+                  : (NI == 2 ? launch_gemm_qd_multi<TYPE, 3, 2>(w, n, xp, plane_stride, out, T, S, s)               \
+                             : launch_gemm_qd_multi<TYPE, 3, 1>(w, n, xp, plane_stride, out, T, S, s))
+  switch (w[0].type) {
+    case TL_Q4_K: TL_QD_MULTI(TL_Q4_K); break;
+    case TL_Q6_K: TL_QD_MULTI(TL_Q6_K); break;
+    case TL_Q8_0: TL_QD_MULTI(TL_Q8_0); break;
+    case TL_Q8_K: TL_QD_MULTI(TL_Q8_K); break;
+    default: return 0;
+  }
+#undef TL_QD_MULTI
+  if (rc) return rc;
+  if (S > 1)
+    for (int i = 0; i < n; ++i) defer[i]->got = {out[i], (size_t)T * w[i].rows, S};
+  *merged = true;
   return 0;
 }
 

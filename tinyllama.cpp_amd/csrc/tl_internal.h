@@ -222,6 +222,10 @@ int tl_launch_split(int mode, const float* x, const float* aux, void* planes, si
                     float* xout = nullptr);
 int tl_launch_gemm_q(const QW& w, const void* planes, size_t plane_stride, float* y, const float* resid, int T,
                      int terms, hipStream_t s, GemmDefer* defer = nullptr);
+// up to three matrices over the same planes in one launch when that changes no bit (tl_gemm.hip); *merged = false: nothing
+// was launched
+int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_stride, float* const* y, int T, int terms,
+                           hipStream_t s, GemmDefer* const* defer, bool* merged);
 // y = (resid ? resid : 0) + the pending sums (what the GEMM launch would have run itself)
 int tl_launch_ksplit_reduce(const GemmParts& g, const float* resid, float* y, hipStream_t s);
 
@@ -266,7 +270,7 @@ void tl_peer_destroy(TlPeer* p);
 int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,
                             const int* pos_dev, const int* seq_dev, int T, int nq, int nkv, int hd, int max_seq, int n_seq,
                             hipStream_t s, const GemmParts* pq = nullptr, const GemmParts* pk = nullptr,
-                            const GemmParts* pv = nullptr);
+                            const GemmParts* pv = nullptr, int start_pos = 0);
 bool tl_batch_attn_supported(int nh, int nkv, int hd);
 int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_t seq_stride, float* out, const int* pos_dev,
                          const int* seq_dev, int T, int nh, int nkv, int hd, int max_seq, int n_seq, float scale,

@@ -95,6 +95,7 @@ struct tl_model {
     float* part[3] = {nullptr, nullptr, nullptr};
     size_t part_cap = 0;
     GemmParts pend = {nullptr, 0, 0};
+    GemmDefer dq = {}, dk = {}, dv = {};  // q / k / v of the layer in hand (qkv_deferred)
     void* planes = nullptr;    // bf16 [3][plane_stride]
     size_t plane_stride = 0;
     float* logits_all = nullptr;  // [cap][vocab], only when all logits were asked for
@@ -1099,6 +1100,36 @@ static int project_residual(tl_model* m, const tl_qweight* w, int T, hipStream_t
   p.pend = d.got;
   return 0;
 }
+// q, k, v of the T tokens whose planes are staged: into pf.qb / kb / vb, or (K split and the workspaces there) as partial
+// tiles described by pf.dq / dk / dv .got for the RoPE + cache-write kernel to sum
+static int qkv_deferred(tl_model* m, LayerW& L, int T, hipStream_t s) {
+  tl_model::Prefill& p = m->pf;
+  const int terms = m->prefill_terms ? m->prefill_terms : tl_gemm_default_terms();
+  const size_t ps = p.plane_stride;
+  p.dq = {p.part[0], p.part_cap, {nullptr, 0, 0}};
+  p.dk = {p.part[1], p.part_cap, {nullptr, 0, 0}};
+  p.dv = {p.part[2], p.part_cap, {nullptr, 0, 0}};
+  const bool defer = p.part_cap != 0;
+  // one launch where that changes no bit (runs of equal formats: Q4_K_M files hold v as Q6_K in some layers)
+  bool merged = false;
+  const QW w3[3] = {qw_view(L.q[TL_T_ATTN_Q]), qw_view(L.q[TL_T_ATTN_K]), qw_view(L.q[TL_T_ATTN_V])};
+  float* const y3[3] = {p.qb, p.kb, p.vb};
+  GemmDefer* const d3[3] = {&p.dq, &p.dk, &p.dv};
+  const int same = w3[2].type == w3[0].type ? 3 : 2;
+  if (defer && w3[1].type == w3[0].type) TL_TRY(tl_launch_gemm_q_multi(w3, same, p.planes, ps, y3, T, terms, s, d3, &merged));
+  if (merged) {
+    if (same == 2) TL_TRY(tl_launch_gemm_q(w3[2], p.planes, ps, p.vb, nullptr, T, terms, s, &p.dv));
+    return 0;
+  }
+  TL_HIP(hipEventRecord(p.fork, s));
+  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
+  TL_TRY(tl_launch_gemm_q(w3[0], p.planes, ps, p.qb, nullptr, T, terms, s, defer ? &p.dq : nullptr));
+  TL_TRY(tl_launch_gemm_q(w3[1], p.planes, ps, p.kb, nullptr, T, terms, p.side, defer ? &p.dk : nullptr));
+  TL_TRY(tl_launch_gemm_q(w3[2], p.planes, ps, p.vb, nullptr, T, terms, p.side, defer ? &p.dv : nullptr));
+  TL_HIP(hipEventRecord(p.join, p.side));
+  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  return 0;
+}
 static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream_t s) {
   const tl_model_config& c = m->cfg;
   tl_model::Prefill& p = m->pf;
@@ -1109,16 +1140,24 @@ static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream
   const float scale = 1.0f / sqrtf((float)hd);
   (void)H;
   TL_TRY(split_residual(m, L.attn_norm, T, s));
-  TL_HIP(hipEventRecord(p.fork, s));
-  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
-  TL_HIP(hipEventRecord(p.join, p.side));
-  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
-  TL_TRY(tl_rope_batch(p.qb, p.kb, m->rope, T, m->nh_l, m->nkv_l, hd, start_pos, c.max_position_embeddings, 1, s));
-  TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
-  TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+  if (p.part_cap && m->tp == 1) {
+    // q | k | v with their K-split sums left to ONE RoPE + cache-write kernel (instead of three reductions, the rotation
+    // and two cache copies), merged into one launch where that changes no bit
+    TL_TRY(qkv_deferred(m, L, T, s));
+    TL_TRY(tl_launch_batch_rope_kv(p.qb, p.kb, p.vb, m->kc(l), m->vc(l), 0, m->rope, nullptr, nullptr, T, m->nh_l, m->nkv_l, hd,
+                                   c.max_position_embeddings, 1, s, &p.dq.got, &p.dk.got, &p.dv.got, start_pos));
+  } else {
+    TL_HIP(hipEventRecord(p.fork, s));
+    TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side));
+    TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side));
+    TL_HIP(hipEventRecord(p.join, p.side));
+    TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+    TL_TRY(tl_rope_batch(p.qb, p.kb, m->rope, T, m->nh_l, m->nkv_l, hd, start_pos, c.max_position_embeddings, 1, s));
+    TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+    TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
+  }
   TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
                                     m->nkv_l, hd, scale, s));
   TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
@@ -1132,14 +1171,21 @@ static int prefill_mlp_half(tl_model* m, int l, int T, hipStream_t s) {
   const size_t ps = p.plane_stride;
   (void)c;
   TL_TRY(split_residual(m, L.ffn_norm, T, s));
-  TL_HIP(hipEventRecord(p.fork, s));
-  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
   GemmDefer dg = {p.part[0], p.part_cap, {nullptr, 0, 0}}, du = {p.part[1], p.part_cap, {nullptr, 0, 0}};
   const bool defer = p.part_cap != 0;
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_GATE]), p.planes, ps, p.gb, nullptr, T, terms, s, defer ? &dg : nullptr));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_FFN_UP]), p.planes, ps, p.ub, nullptr, T, terms, p.side, defer ? &du : nullptr));
-  TL_HIP(hipEventRecord(p.join, p.side));
-  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  bool merged = false;  // gate | up in one launch where that changes no bit
+  const QW w2[2] = {qw_view(L.q[TL_T_FFN_GATE]), qw_view(L.q[TL_T_FFN_UP])};
+  float* const y2[2] = {p.gb, p.ub};
+  GemmDefer* const d2[2] = {&dg, &du};
+  if (defer && w2[0].type == w2[1].type) TL_TRY(tl_launch_gemm_q_multi(w2, 2, p.planes, ps, y2, T, terms, s, d2, &merged));
+  if (!merged) {
+    TL_HIP(hipEventRecord(p.fork, s));
+    TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
+    TL_TRY(tl_launch_gemm_q(w2[0], p.planes, ps, p.gb, nullptr, T, terms, s, defer ? &dg : nullptr));
+    TL_TRY(tl_launch_gemm_q(w2[1], p.planes, ps, p.ub, nullptr, T, terms, p.side, defer ? &du : nullptr));
+    TL_HIP(hipEventRecord(p.join, p.side));
+    TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  }
   TL_TRY(tl_launch_split(2, p.gb, p.ub, p.planes, ps, T, m->I_l, terms, 0.f, s, &dg.got, &du.got));
   return project_residual(m, L.q[TL_T_FFN_DOWN], T, s);
 }
@@ -1301,25 +1347,17 @@ static int batch_attn_half(tl_model* m, int l, int T, hipStream_t s) {
   const float scale = 1.0f / sqrtf((float)hd);
   (void)H;
   TL_TRY(split_residual(m, L.attn_norm, T, s));
-  TL_HIP(hipEventRecord(p.fork, s));
-  TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));
-  GemmDefer dq = {p.part[0], p.part_cap, {nullptr, 0, 0}}, dk = {p.part[1], p.part_cap, {nullptr, 0, 0}},
-            dv = {p.part[2], p.part_cap, {nullptr, 0, 0}};
-  const bool defer = p.part_cap != 0;
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_Q]), p.planes, ps, p.qb, nullptr, T, terms, s, defer ? &dq : nullptr));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_K]), p.planes, ps, p.kb, nullptr, T, terms, p.side, defer ? &dk : nullptr));
-  TL_TRY(tl_launch_gemm_q(qw_view(L.q[TL_T_ATTN_V]), p.planes, ps, p.vb, nullptr, T, terms, p.side, defer ? &dv : nullptr));
-  TL_HIP(hipEventRecord(p.join, p.side));
-  TL_HIP(hipStreamWaitEvent(s, p.join, 0));
+  TL_TRY(qkv_deferred(m, L, T, s));
   TL_TRY(tl_launch_batch_rope_kv(p.qb, p.kb, p.vb, m->bkc(l), m->bvc(l), m->kv_layer_elems, m->rope, m->bt.pos, m->bt.seq, T,
-                                 m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s, &dq.got, &dk.got, &dv.got));
+                                 m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s, &p.dq.got, &p.dk.got,
+                                 &p.dv.got));
   TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
                               m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s));
   TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
   return project_residual(m, L.q[TL_T_ATTN_OUTPUT], T, s);
 }
 
-// The same step for a FEW sequences (T <= batch_gemv_max, default 8): the projections as multi-vector GEMVs
+// The same step for a FEW sequences (T <= batch_gemv_max, default 4): the projections as multi-vector GEMVs
 // (gemv_nv_kernel: one pass over the weights for up to four tokens, RMSNorm / residual / SwiGLU fused as in the
 // single-sequence step) instead of matrix-core GEMMs, whose cost per step does not fall below that of 128 tokens.
 static bool batch_gemv_ok(const tl_model* m) {
@@ -1479,7 +1517,8 @@ extern "C" int tl_model_batch_init(tl_model* m, int max_batch) {
   TL_HIP(hipMalloc(&b.seq, sizeof(int) * kPrefillChunk));
   TL_HIP(hipMalloc(&b.last_h, sizeof(float) * (size_t)max_batch * m->cfg.hidden_size));
   b.max_batch = max_batch;
-  b.gemv_max = batch_gemv_ok(m) ? 8 : 0;  // two passes of four vectors cost what one step of the direct small-token GEMM does
+  b.gemv_max = batch_gemv_ok(m) ? 4 : 0;  // one pass of up to four vectors: 2.5 / 4.0 / 4.1 ms per step for 2 / 3 / 4 sequences; the
+                                          // direct small-token GEMM route costs 5.3 ms whatever the count (two GEMV passes: 6.1 - 7.8)
   if (const char* e = getenv("TL_BATCH_GEMV_MAX")) {  // A/B runs: 0 = always the matrix-core GEMMs
     const int v = atoi(e);
     if (v >= 0 && v <= 64 && b.gemv_max) b.gemv_max = v;

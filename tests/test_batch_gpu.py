@@ -216,6 +216,7 @@ def test_deferred_ksplit_reductions_are_bit_identical(pkg, monkeypatch):
         for defer, merge in (("0", "1"), ("1", "0"), ("1", "1")):
             monkeypatch.setenv("TL_GEMM_DEFER", defer)  # read when the model's prefill workspaces are made
             monkeypatch.setenv("TL_GEMM_MERGE", merge)  # q | k | v and gate | up in one launch each (needs DEFER)
+            monkeypatch.setenv("TL_ATTN_PLANES", defer)  # batched attention writes the attn_output GEMM's planes itself
             m = E.Model(cfg).load(tensors)
             m.batch_init(12)
             logits, ids = m.batch_prefill_packed(prompts)

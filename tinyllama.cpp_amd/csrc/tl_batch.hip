@@ -19,6 +19,7 @@
 #include "tl_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -90,6 +91,13 @@ struct BatchAttnArgs {
   const int* seq;
   int nh, nkv, max_seq, n_seq;
   float scale;
+  // planes != NULL: the output goes straight into the activation planes of the attn_output GEMM (what
+  // split_kernel<SPLIT_PLAIN> would make of `out`, bit for bit: bf16 planes [np][plane_stride] of the [T][nh * hd]
+  // matrix + the sums of its 32-column blocks [nh * hd / 32][tpad]); `out` is then not written
+  __bf16* planes;
+  size_t plane_stride;
+  float* xsum;
+  int np, tpad;
 };
 
 // One workgroup per (kv head, token, head-group part): the G query heads of the group share every K/V row read.
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
   constexpr int NW = 4, LP = HD / 4, PP = 64 / LP, U = 8, RECL = HD + 4;
   __shared__ __attribute__((aligned(16))) float part[NW * G * RECL];
   __shared__ float red[16];
+  __shared__ __attribute__((aligned(16))) float outbuf[G * HD];
   const int kvh = blockIdx.x, tok = blockIdx.y;
   const int head0 = (kvh * gridDim.z + blockIdx.z) * G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,7 +211,36 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
       const float* rec = part + (size_t)(w * G + g) * RECL;
       o += rec[d] * exp_diff(rec[HD], M);
     }
-    a.out[((size_t)tok * a.nh + head0 + g) * HD + d] = o * red[8 + g];
+    if (a.planes) outbuf[i] = o * red[8 + g];
+    else a.out[((size_t)tok * a.nh + head0 + g) * HD + d] = o * red[8 + g];
+  }
+  if (!a.planes) return;  // uniform
+  __syncthreads();
+  // split_kernel<SPLIT_PLAIN>'s body for this workgroup's G * HD consecutive columns: 8 columns per thread, the sum of a
+  // 32-column block over 4 neighbouring threads
+  const int K = a.nh * HD;
+  if (tid < G * HD / 8) {
+    const int i0 = head0 * HD + tid * 8;
+    float v[8];
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(outbuf + tid * 8), hi = *reinterpret_cast<const f32x4*>(outbuf + tid * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[e] = lo[e];
+      v[4 + e] = hi[e];
+    }
+    float bs = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    bs += __shfl_xor(bs, 1);
+    bs += __shfl_xor(bs, 2);
+    if ((tid & 3) == 0) a.xsum[(size_t)(i0 >> 5) * a.tpad + tok] = bs;
+    for (int p = 0; p < a.np; ++p) {
+      bf16x8 b;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        b[e] = (__bf16)v[e];
+        v[e] -= (float)b[e];
+      }
+      *reinterpret_cast<bf16x8*>(a.planes + p * a.plane_stride + (size_t)tok * K + i0) = b;
+    }
   }
 }
 
@@ -295,11 +333,19 @@ bool tl_batch_attn_supported(int nh, int nkv, int hd) {
 
 int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_t seq_stride, float* out, const int* pos_dev,
                          const int* seq_dev, int T, int nh, int nkv, int hd, int max_seq, int n_seq, float scale,
-                         hipStream_t s) {
+                         hipStream_t s, void* planes, size_t plane_stride, int terms) {
   TL_REQUIRE(tl_batch_attn_supported(nh, nkv, hd), "batched decode attention: unsupported head configuration %d/%d/%d", nh,
              nkv, hd);
   TL_REQUIRE(q && kc && vc && out && pos_dev && seq_dev && T > 0 && T <= 65535, "batched decode attention: bad argument");
-  BatchAttnArgs a = {q, kc, vc, seq_stride, out, pos_dev, seq_dev, nh, nkv, max_seq, n_seq, scale};
+  BatchAttnArgs a = {q, kc, vc, seq_stride, out, pos_dev, seq_dev, nh, nkv, max_seq, n_seq, scale, nullptr, 0, nullptr, 0, 0};
+  if (planes) {  // layout as tl_launch_split makes it: three bf16 planes, then the block sums
+    TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)nh * hd, "batched decode attention: activation planes too small");
+    a.planes = static_cast<__bf16*>(planes);
+    a.plane_stride = plane_stride;
+    a.xsum = reinterpret_cast<float*>(a.planes + 3 * plane_stride);
+    a.np = terms == 1 ? 1 : terms == 3 ? 2 : 3;
+    a.tpad = (int)tl_gemm_padded_tokens(T);
+  }
   return hd == 64 ? launch_attn_h<64>(a, T, s) : launch_attn_h<128>(a, T, s);
 }
 

@@ -1340,9 +1340,9 @@ int launch_gemm_qd_ni(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   return launch_gemm_qd_inst<TYPE, NPX, NI, 4>(w, xp, ps, y, resid, T, S, s);
 }
 // n matrices in one launch (gemm_qd_kernel NSEG = 3), four waves per workgroup; S slices for every one of them
-template <int TYPE, int NPX, int NI>
-int launch_gemm_qd_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, int T, int S, hipStream_t s) {
-  constexpr int NW = 4, BN = 32 * NI, BMD = 32 * NW;
+template <int TYPE, int NPX, int NI, int NW>
+int launch_gemm_qd_multi_nw(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, int T, int S, hipStream_t s) {
+  constexpr int BN = 32 * NI, BMD = 32 * NW;
   constexpr size_t lds = 2 * ((size_t)2 * NPX * BN * LROW * sizeof(__bf16) + 2 * BN * sizeof(float));
   const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
   const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + BN - 1) / BN;
@@ -1358,6 +1358,20 @@ int launch_gemm_qd_multi(const QW* w, int n, const __bf16* xp, size_t ps, float*
   gemm_qd_kernel<TYPE, NPX, NI, NW, 3><<<dim3(mt * ntiles, S), dim3(64 * NW), lds, s>>>(g, xp, ps, xsum, tpad, nullptr, T, mt, ntiles);
   TL_HIP(hipGetLastError());
   return 0;
+}
+// four waves per workgroup. Eight (the waves of a workgroup share the staged activation tile) measured slower on merged
+// launches even where they still fill the chip: 32 sequences 5.67 ms per step against 5.56 (TL_GEMM_MERGE_NW=8 for A/B
+// runs; the choice changes no bit)
+template <int TYPE, int NPX, int NI>
+int launch_gemm_qd_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, int T, int S, hipStream_t s) {
+  static int force = -1;
+  if (force < 0) {
+    const char* e = getenv("TL_GEMM_MERGE_NW");
+    force = e ? atoi(e) : 0;
+  }
+  const bool eight = force == 8;
+  return eight ? launch_gemm_qd_multi_nw<TYPE, NPX, NI, 8>(w, n, xp, ps, out, T, S, s)
+               : launch_gemm_qd_multi_nw<TYPE, NPX, NI, 4>(w, n, xp, ps, out, T, S, s);
 }
 template <int TYPE>
 int launch_gemm_qd(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, int terms, hipStream_t s) {

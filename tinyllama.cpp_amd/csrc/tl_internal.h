@@ -274,7 +274,7 @@ int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float
 bool tl_batch_attn_supported(int nh, int nkv, int hd);
 int tl_launch_batch_attn(const float* q, const float* kc, const float* vc, size_t seq_stride, float* out, const int* pos_dev,
                          const int* seq_dev, int T, int nh, int nkv, int hd, int max_seq, int n_seq, float scale,
-                         hipStream_t s);
+                         hipStream_t s, void* planes = nullptr, size_t plane_stride = 0, int terms = 0);
 int tl_launch_batch_argmax_advance(const float* logits, int T, int V, int* tokens_dev, int* pos_dev, int* ids_out_dev,
                                    hipStream_t s);
 

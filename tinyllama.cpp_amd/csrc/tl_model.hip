@@ -1351,9 +1351,17 @@ static int batch_attn_half(tl_model* m, int l, int T, hipStream_t s) {
   TL_TRY(tl_launch_batch_rope_kv(p.qb, p.kb, p.vb, m->bkc(l), m->bvc(l), m->kv_layer_elems, m->rope, m->bt.pos, m->bt.seq, T,
                                  m->nh_l, m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, s, &p.dq.got, &p.dk.got,
                                  &p.dv.got));
-  TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
-                              m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s));
-  TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+  // the attention output goes straight into the planes of the attn_output GEMM (no split launch; TL_ATTN_PLANES=0 keeps
+  // the launch, for A/B runs and the bit-identity test)
+  const char* ap = getenv("TL_ATTN_PLANES");
+  if (ap && atoi(ap) == 0) {
+    TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
+                                m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s));
+    TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+  } else {
+    TL_TRY(tl_launch_batch_attn(p.qb, m->bkc(l), m->bvc(l), m->kv_layer_elems, p.ab, m->bt.pos, m->bt.seq, T, m->nh_l,
+                                m->nkv_l, hd, c.max_position_embeddings, m->bt.max_batch, scale, s, p.planes, ps, terms));
+  }
   return project_residual(m, L.q[TL_T_ATTN_OUTPUT], T, s);
 }
 

@@ -222,8 +222,9 @@ def test_deferred_ksplit_reductions_are_bit_identical(pkg, monkeypatch):
             logits, ids = m.batch_prefill_packed(prompts)
             step, nxt = m.batch_decode(list(ids), [len(p) for p in prompts], list(range(12)))
             more = m.batch_generate_greedy(list(nxt), [len(p) + 1 for p in prompts], list(range(12)), 3)
-            _, all_logits = m.prefill(long_prompt, all_logits=True)
-            got[defer + merge] = [np.array(x) for x in (logits, ids, step, nxt, more, all_logits)]
+            _, all_logits = m.prefill(long_prompt, all_logits=True)       # 100 tokens: integer-plane kernel, 128-token tiles
+            _, all_logits40 = m.prefill(long_prompt[:40], all_logits=True)  # 40 tokens: its 64-token tiles
+            got[defer + merge] = [np.array(x) for x in (logits, ids, step, nxt, more, all_logits, all_logits40)]
             m.free()
         for other in ("10", "11"):
             for a, b in zip(got["01"], got[other]):

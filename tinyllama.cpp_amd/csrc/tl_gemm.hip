@@ -476,27 +476,46 @@ constexpr size_t gemm_qi_lds_bytes() {
 #ifndef TL_QI_SETS
 #define TL_QI_SETS 3
 #endif
-template <int TYPE, int NPX, int BN, int BM>
-__global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(QW w, const __bf16* __restrict__ xp, size_t plane_stride,
+// NSEG = 3: up to three matrices that share the activation planes (q | k | v, gate | up: same K, same format) in ONE
+// launch; the row tiles of the matrices follow each other in the tile index and every tile computes exactly what it would
+// in a launch of its own: MSegs::mt_end = cumulative row-tile counts, S = K slices of each matrix (gridDim.y is the
+// largest; workgroups beyond a matrix's own count leave at once). No residual in that form.
+struct MSegs {
+  QW w[3];
+  float* y[3];
+  int mt_end[3];
+  int S[3];
+};
+template <int TYPE, int NPX, int BN, int BM, int NSEG>
+__global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(MSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
                                                                 const float* __restrict__ xsum, int tpad,
-                                                                float* __restrict__ y, const float* __restrict__ resid,
+                                                                const float* __restrict__ resid,
                                                                 int T, int mtiles, int ntiles) {
   constexpr int NI = BN / 64, MI = BM / 64;
   constexpr bool PER16 = TYPE == TL_Q6_K;  // scale granularity: 16 columns (one MFMA) or the whole 32-column step
   constexpr int WPL = BM * LROW, XPL = BN * LROW;
   constexpr size_t BUF_BYTES = (WPL + NPX * XPL) * sizeof(__bf16) + (BM * 3 + BN) * sizeof(float);
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int M = w.rows, K = w.cols;
   const int total = mtiles * ntiles;
   int tile = blockIdx.x;
   if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
-  const int nt = tile / mtiles, mt = tile - nt * mtiles;
+  const int nt = tile / mtiles;
+  int mt = tile - nt * mtiles, seg = 0;
+  if (NSEG > 1) {
+    seg = (mt >= segs.mt_end[0]) + (mt >= segs.mt_end[1]);
+    if (seg) mt -= segs.mt_end[seg - 1];
+  }
+  const int nslices = NSEG > 1 ? segs.S[seg] : (int)gridDim.y;
+  if ((int)blockIdx.y >= nslices) return;  // (uniform over the workgroup, before any barrier)
+  const QW w = segs.w[seg];
+  float* __restrict__ y = segs.y[seg];
+  const int M = w.rows, K = w.cols;
   const int m0 = mt * BM, n0 = nt * BN;
-  const int nk_all = K / GB_K, kper = (nk_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int nk_all = K / GB_K, kper = (nk_all + nslices - 1) / nslices;
   const int kbase = (int)blockIdx.y * kper;
   const int nk = nk_all - kbase < kper ? nk_all - kbase : kper, last = kbase + nk - 1;
   const int nk3 = (nk + TL_QI_SETS - 1) / TL_QI_SETS * TL_QI_SETS;  // both roles run a multiple of the rotation length
-  if (gridDim.y > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
+  if (nslices > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
   auto wbuf = [&](int b) { return reinterpret_cast<__bf16*>(lds_raw + (size_t)b * BUF_BYTES); };
   auto fbuf = [&](int b) {
     return reinterpret_cast<float*>(lds_raw + (size_t)b * BUF_BYTES + (WPL + NPX * XPL) * sizeof(__bf16));
@@ -711,16 +730,9 @@ constexpr int QD_SETS = TL_QD_SETS;  // weight register sets = 64-column steps a
 __device__ __forceinline__ u32x2 half_swap(unsigned a, unsigned b) {  // -> {[a.lo | b.lo], [a.hi | b.hi]} (32-lane halves)
   return __builtin_amdgcn_permlane32_swap(a, b, false, false);
 }
-// NSEG = 3: up to three matrices that share the activation planes (q | k | v, gate | up: same K, same format) in ONE
-// launch; the row tiles of the matrices follow each other in the tile index, every tile computes exactly what it would
-// in a launch of its own (QDSegs::mt_end = cumulative row-tile counts; no residual in that form).
-struct QDSegs {
-  QW w[3];
-  float* y[3];
-  int mt_end[3];
-};
+// NSEG = 3: several matrices in one launch as in gemm_qi_ws_kernel (MSegs; here all with gridDim.y slices)
 template <int TYPE, int NPX, int NI, int NW, int NSEG>
-__global__ __launch_bounds__(64 * NW) void gemm_qd_kernel(QDSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
+__global__ __launch_bounds__(64 * NW) void gemm_qd_kernel(MSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
                                                           const float* __restrict__ xsum, int tpad,
                                                           const float* __restrict__ resid, int T, int mtiles, int ntiles) {
   constexpr int BN = 32 * NI, NT = 64 * NW, BMD = 32 * NW;
@@ -1231,16 +1243,9 @@ int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
   return launch_gemm_ws_bn<TYPE, NP, NT, BM, GB_N>(w, xp, ps, y, resid, T, s);
 }
 
-template <int TYPE, int NPX, int BN, int BM>
-int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
-  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + BN - 1) / BN;
-  constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
-  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
-  TL_TRY(tl_raise_lds_limit(gemm_qi_ws_kernel<TYPE, NPX, BN, BM>, (int)lds, lds_raised));
-  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
-  const int tpad = (int)tl_gemm_padded_tokens(T);
-  const int tiles = mtiles * ntiles, nk_all = w.cols / GB_K;
-  int S = 1;  // split K as in launch_gemm_ws_bn
+// K slices of an integer-plane launch of `tiles` tiles
+static int qi_slices(int tiles, int nk_all) {
+  int S = 1;
   if (ksplit_enabled() && tiles < 2 * gemm_num_cus()) {
     S = (2 * gemm_num_cus() + tiles - 1) / tiles;
     if (S > 8) S = 8;
@@ -1249,13 +1254,59 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
     const int kper = (nk_all + S - 1) / S;
     S = (nk_all + kper - 1) / kper;
   }
+  return S;
+}
+static bool qi_narrow_always() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("TL_GEMM_QI_BN");  // 64: 64-token tiles for every problem size (A/B runs)
+    v = e && atoi(e) == 64;
+  }
+  return v != 0;
+}
+// n matrices in one launch (gemm_qi_ws_kernel NSEG = 3); S[i] slices for matrix i, outputs / partial tiles in out[i]
+template <int TYPE, int NPX, int BN, int BM>
+int launch_gemm_qi_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, int T, hipStream_t s) {
+  constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_qi_ws_kernel<TYPE, NPX, BN, BM, 3>, (int)lds, lds_raised));
+  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
+  const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + BN - 1) / BN;
+  MSegs g = {};
+  int mt = 0, smax = 1;
+  for (int i = 0; i < 3; ++i) {
+    const int k = i < n ? i : n - 1;  // (unused slots repeat the last matrix; their tile range is empty)
+    g.w[i] = w[k];
+    g.y[i] = out[k];
+    g.S[i] = S[k];
+    if (i < n) mt += (w[i].rows + BM - 1) / BM;
+    g.mt_end[i] = mt;
+    if (S[k] > smax) smax = S[k];
+  }
+  gemm_qi_ws_kernel<TYPE, NPX, BN, BM, 3><<<dim3(mt * ntiles, smax), dim3(WS_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, nullptr, T, mt, ntiles);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+template <int TYPE, int NPX, int BN, int BM>
+int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
+  const int mtiles = (w.rows + BM - 1) / BM, ntiles = (T + BN - 1) / BN;
+  constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_qi_ws_kernel<TYPE, NPX, BN, BM, 1>, (int)lds, lds_raised));
+  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
+  const int tpad = (int)tl_gemm_padded_tokens(T);
+  const int tiles = mtiles * ntiles;
+  int S = qi_slices(tiles, w.cols / GB_K);  // split K as in launch_gemm_ws_bn
   float* part = nullptr;
   bool deferred = false;
   TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
+  MSegs g = {};
+  g.w[0] = w;
+  g.y[0] = S == 1 ? y : part;
   if (S == 1) {
-    gemm_qi_ws_kernel<TYPE, NPX, BN, BM><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(w, xp, ps, xsum, tpad, y, resid, T, mtiles, ntiles);
+    gemm_qi_ws_kernel<TYPE, NPX, BN, BM, 1><<<dim3(tiles), dim3(WS_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, mtiles, ntiles);
   } else {
-    gemm_qi_ws_kernel<TYPE, NPX, BN, BM><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(w, xp, ps, xsum, tpad, part, nullptr, T, mtiles, ntiles);
+    gemm_qi_ws_kernel<TYPE, NPX, BN, BM, 1><<<dim3(tiles, S), dim3(WS_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, nullptr, T, mtiles, ntiles);
     ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
   }
   TL_HIP(hipGetLastError());
@@ -1263,11 +1314,7 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
 }
 template <int TYPE, int NPX, int BM>
 int launch_gemm_qi_np(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
-  static int narrow_always = -1;
-  if (narrow_always < 0) {
-    const char* e = getenv("TL_GEMM_QI_BN");  // 64: 64-token tiles for every problem size (A/B runs)
-    narrow_always = e && atoi(e) == 64;
-  }
+  const bool narrow_always = qi_narrow_always();
   return (T <= 64 || narrow_always) ? launch_gemm_qi_bn<TYPE, NPX, 64, BM>(w, xp, ps, y, resid, T, s)
                                     : launch_gemm_qi_bn<TYPE, NPX, GB_N, BM>(w, xp, ps, y, resid, T, s);
 }
@@ -1294,7 +1341,7 @@ int launch_gemm_qd_inst(const QW& w, const __bf16* xp, size_t ps, float* y, cons
   float* part = nullptr;
   bool deferred = false;
   TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
-  QDSegs g = {};
+  MSegs g = {};
   g.w[0] = w;
   g.y[0] = S == 1 ? y : part;
   if (S == 1) {
@@ -1346,7 +1393,7 @@ int launch_gemm_qd_multi_nw(const QW* w, int n, const __bf16* xp, size_t ps, flo
   constexpr size_t lds = 2 * ((size_t)2 * NPX * BN * LROW * sizeof(__bf16) + 2 * BN * sizeof(float));
   const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
   const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + BN - 1) / BN;
-  QDSegs g = {};
+  MSegs g = {};
   int mt = 0;
   for (int i = 0; i < 3; ++i) {
     const int k = i < n ? i : n - 1;  // (unused slots repeat the last matrix; their tile range is empty)
@@ -1513,9 +1560,9 @@ static int launch_gemm_dispatch(const QW& w, const __bf16* xp, size_t plane_stri
 }
 
 // Up to three matrices over the same activation planes (q | k | v, gate | up) in one launch of the direct small-token
-// kernel. Taken only when that changes no bit: all matrices of one format and width, the token count on the direct
-// route, and the same number of K slices for each as its own launch would use (then every tile computes what it would
-// alone). Outputs: with one slice y[i] directly; with more, the partial tiles go to defer[i] (required) for the consumer
+// kernel or of the integer-plane kernel. Taken only when that changes no bit: all matrices of one format and width, and
+// for every matrix the number of K slices its own launch would use (the direct kernel needs them equal; then every tile
+// computes what it would alone). Outputs: with one slice y[i] directly; with more, the partial tiles go to defer[i] (required) for the consumer
 // to sum. *merged = false: nothing was launched, the caller runs the matrices one by one.
 int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_stride, float* const* y, int T, int terms,
                            hipStream_t s, GemmDefer* const* defer, bool* merged) {
@@ -1523,24 +1570,32 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
   const char* e = getenv("TL_GEMM_MERGE");  // 0: one launch per matrix (A/B runs; read at every call)
   const bool on = e ? atoi(e) != 0 : true;
   const char* q = getenv("TL_GEMM_INT");
-  if (!on || (q && atoi(q) == 0) || n < 2 || n > 3 || T <= 0 || terms == 1 || T > gemm_direct_max()) return 0;
-  const int NI = T > 32 ? 2 : 1, ntiles = (T + 32 * NI - 1) / (32 * NI);
-  int S = 0;
-  for (int i = 0; i < n; ++i) {
+  const char* bm = getenv("TL_GEMM_BM");
+  if (!on || (q && atoi(q) == 0) || n < 2 || n > 3 || T <= 0 || terms == 1) return 0;
+  for (int i = 0; i < n; ++i)
     if (w[i].type != w[0].type || w[i].cols != w[0].cols || w[i].cols % 64 != 0 || w[i].rows <= 0) return 0;
-    int nw = 0, si = 1;
-    qd_shape(w[i].rows, w[i].cols, ntiles, &nw, &si);
-    if (i && si != S) return 0;
-    S = si;
+  const bool direct = T <= gemm_direct_max();
+  if (!direct && bm && atoi(bm) == 64) return 0;  // (the merged integer-plane launch exists for 128-row tiles only)
+  // K slices of every matrix as its own launch would choose them
+  const int NI = T > 32 ? 2 : 1, BN = (T <= 64 || qi_narrow_always()) ? 64 : GB_N;
+  const int ntiles = direct ? (T + 32 * NI - 1) / (32 * NI) : (T + BN - 1) / BN;
+  int S[3] = {1, 1, 1};
+  for (int i = 0; i < n; ++i) {
+    if (direct) {
+      int nw = 0;
+      qd_shape(w[i].rows, w[i].cols, ntiles, &nw, &S[i]);
+      if (S[i] != S[0]) return 0;  // (the direct kernel takes one slice count per launch)
+    } else {
+      S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K);
+    }
   }
   TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w[0].cols, "tl_launch_gemm_q_multi: activation planes too small");
   float* out[3] = {nullptr, nullptr, nullptr};
   for (int i = 0; i < n; ++i) {
-    if (S == 1) {
+    if (S[i] == 1) {
       out[i] = y[i];
-      if (defer && defer[i]) defer[i]->got = {nullptr, 0, 0};
     } else {
-      const size_t floats = (size_t)S * T * w[i].rows;
+      const size_t floats = (size_t)S[i] * T * w[i].rows;
       if (!defer || !defer[i] || !defer[i]->buf || defer[i]->cap_floats < floats) return 0;
       out[i] = defer[i]->buf;
     }
@@ -1548,21 +1603,34 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
   const __bf16* xp = static_cast<const __bf16*>(planes);
   int rc = 0;
 #define TL_QD_MULTI(TYPE)                                                                                           \
-  rc = terms == 3 ? (NI == 2 ? launch_gemm_qd_multi<TYPE, 2, 2>(w, n, xp, plane_stride, out, T, S, s)               \
-                             : launch_gemm_qd_multi<TYPE, 2, 1>(w, n, xp, plane_stride, out, T, S, s))              \
-                  : (NI == 2 ? launch_gemm_qd_multi<TYPE, 3, 2>(w, n, xp, plane_stride, out, T, S, s)               \
-                             : launch_gemm_qd_multi<TYPE, 3, 1>(w, n, xp, plane_stride, out, T, S, s))
+  rc = terms == 3 ? (NI == 2 ? launch_gemm_qd_multi<TYPE, 2, 2>(w, n, xp, plane_stride, out, T, S[0], s)            \
+                             : launch_gemm_qd_multi<TYPE, 2, 1>(w, n, xp, plane_stride, out, T, S[0], s))           \
+                  : (NI == 2 ? launch_gemm_qd_multi<TYPE, 3, 2>(w, n, xp, plane_stride, out, T, S[0], s)            \
+                             : launch_gemm_qd_multi<TYPE, 3, 1>(w, n, xp, plane_stride, out, T, S[0], s))
+#define TL_QI_MULTI(TYPE)                                                                                           \
+  rc = terms == 3 ? (BN == 64 ? launch_gemm_qi_multi<TYPE, 2, 64, 128>(w, n, xp, plane_stride, out, S, T, s)        \
+                              : launch_gemm_qi_multi<TYPE, 2, GB_N, 128>(w, n, xp, plane_stride, out, S, T, s))     \
+                  : (BN == 64 ? launch_gemm_qi_multi<TYPE, 3, 64, 128>(w, n, xp, plane_stride, out, S, T, s)        \
+                              : launch_gemm_qi_multi<TYPE, 3, GB_N, 128>(w, n, xp, plane_stride, out, S, T, s))
+#define TL_MULTI(TYPE)        \
+  if (direct) {               \
+    TL_QD_MULTI(TYPE);        \
+  } else {                    \
+    TL_QI_MULTI(TYPE);        \
+  }
   switch (w[0].type) {
-    case TL_Q4_K: TL_QD_MULTI(TL_Q4_K); break;
-    case TL_Q6_K: TL_QD_MULTI(TL_Q6_K); break;
-    case TL_Q8_0: TL_QD_MULTI(TL_Q8_0); break;
-    case TL_Q8_K: TL_QD_MULTI(TL_Q8_K); break;
+    case TL_Q4_K: TL_MULTI(TL_Q4_K) break;
+    case TL_Q6_K: TL_MULTI(TL_Q6_K) break;
+    case TL_Q8_0: TL_MULTI(TL_Q8_0) break;
+    case TL_Q8_K: TL_MULTI(TL_Q8_K) break;
     default: return 0;
   }
+#undef TL_MULTI
+#undef TL_QI_MULTI
 #undef TL_QD_MULTI
   if (rc) return rc;
-  if (S > 1)
-    for (int i = 0; i < n; ++i) defer[i]->got = {out[i], (size_t)T * w[i].rows, S};
+  for (int i = 0; i < n; ++i)
+    if (defer && defer[i]) defer[i]->got = S[i] > 1 ? GemmParts{out[i], (size_t)T * w[i].rows, S[i]} : GemmParts{nullptr, 0, 0};
   *merged = true;
   return 0;
 }

@@ -1353,36 +1353,47 @@ int launch_gemm_qd_inst(const QW& w, const __bf16* xp, size_t ps, float* y, cons
   TL_HIP(hipGetLastError());
   return 0;
 }
+// K slices of a direct-kernel launch of `tiles` tiles that should put about `want` workgroups on the chip
+static int qd_slices(int tiles, int nk_all, int want) {
+  int S = 1;
+  if (ksplit_enabled() && tiles < want) {
+    S = (want + tiles - 1) / tiles;
+    if (S > 8) S = 8;
+    if (S > nk_all / 6) S = nk_all / 6;  // at least six 64-column steps per slice
+    if (S < 1) S = 1;
+    const int kper = (nk_all + S - 1) / S;
+    S = (nk_all + kper - 1) / kper;
+  }
+  return S;
+}
+// set by tl_launch_gemm_q_multi while it launches the matrices of a group one by one (merging switched off, or no
+// buffers for the partial tiles): the slice count it chose for the group, so that the sums do not depend on the route
+static thread_local int t_group_slices = 0;
 // waves per workgroup and K slices of the direct kernel for one matrix: eight waves (256 rows) share a staged activation
-// tile when that still fills the chip, else four
+// tile when that still gives every CU two workgroups, else four waves and about ONE workgroup per CU (measured on the
+// 32-sequence step: gate | up at 2 slices 5.22 ms, 3: 5.29, 5: 5.55; attn_output / ffn_down, 32 tiles each, want their 8)
 static void qd_shape(int rows, int cols, int ntiles, int* NW, int* S) {
-  const int nk_all = cols / 64, want = 2 * gemm_num_cus();
-  auto slices = [&](int tiles) {
-    int S = 1;
-    if (ksplit_enabled() && tiles < want) {
-      S = (want + tiles - 1) / tiles;
-      if (S > 8) S = 8;
-      if (S > nk_all / 6) S = nk_all / 6;  // at least six 64-column steps per slice
-      if (S < 1) S = 1;
-      const int kper = (nk_all + S - 1) / S;
-      S = (nk_all + kper - 1) / kper;
-    }
-    return S;
-  };
+  const int nk_all = cols / 64, cus = gemm_num_cus();
+  if (t_group_slices > 0) {
+    *NW = 4;
+    *S = t_group_slices;
+    return;
+  }
   const int tiles8 = (rows + 255) / 256 * ntiles, tiles4 = (rows + 127) / 128 * ntiles;
-  const int S8 = slices(tiles8);
-  if (tiles8 * S8 >= want) {
+  const int S8 = qd_slices(tiles8, nk_all, 2 * cus);
+  if (tiles8 * S8 >= 2 * cus) {
     *NW = 8;
     *S = S8;
   } else {
     *NW = 4;
-    *S = slices(tiles4);
+    *S = qd_slices(tiles4, nk_all, cus);
   }
 }
 template <int TYPE, int NPX, int NI>
 int launch_gemm_qd_ni(const QW& w, const __bf16* xp, size_t ps, float* y, const float* resid, int T, hipStream_t s) {
   int NW = 4, S = 1;
   qd_shape(w.rows, w.cols, (T + 32 * NI - 1) / (32 * NI), &NW, &S);
+
   if (NW == 8) return launch_gemm_qd_inst<TYPE, NPX, NI, 8>(w, xp, ps, y, resid, T, S, s);
   return launch_gemm_qd_inst<TYPE, NPX, NI, 4>(w, xp, ps, y, resid, T, S, s);
 }
@@ -1571,34 +1582,45 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
   const bool on = e ? atoi(e) != 0 : true;
   const char* q = getenv("TL_GEMM_INT");
   const char* bm = getenv("TL_GEMM_BM");
-  if (!on || (q && atoi(q) == 0) || n < 2 || n > 3 || T <= 0 || terms == 1) return 0;
+  if ((q && atoi(q) == 0) || n < 2 || n > 3 || T <= 0 || terms == 1) return 0;
   for (int i = 0; i < n; ++i)
     if (w[i].type != w[0].type || w[i].cols != w[0].cols || w[i].cols % 64 != 0 || w[i].rows <= 0) return 0;
   const bool direct = T <= gemm_direct_max();
-  if (!direct && bm && atoi(bm) == 64) return 0;  // (the merged integer-plane launch exists for 128-row tiles only)
+  if (!direct && (!on || (bm && atoi(bm) == 64))) return 0;  // (the merged integer-plane launch exists for 128-row tiles only)
   // K slices of every matrix as its own launch would choose them
   const int NI = T > 32 ? 2 : 1, BN = (T <= 64 || qi_narrow_always()) ? 64 : GB_N;
   const int ntiles = direct ? (T + 32 * NI - 1) / (32 * NI) : (T + BN - 1) / BN;
   int S[3] = {1, 1, 1};
-  for (int i = 0; i < n; ++i) {
-    if (direct) {
-      int nw = 0;
-      qd_shape(w[i].rows, w[i].cols, ntiles, &nw, &S[i]);
-      if (S[i] != S[0]) return 0;  // (the direct kernel takes one slice count per launch)
-    } else {
-      S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K);
-    }
+  if (direct) {  // one slice count for the group, from the tiles of the whole launch (four-wave workgroups)
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (w[i].rows + 127) / 128 * ntiles;
+    S[0] = S[1] = S[2] = qd_slices(tiles, w[0].cols / 64, gemm_num_cus());
+  } else {
+    for (int i = 0; i < n; ++i) S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K);
   }
   TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w[0].cols, "tl_launch_gemm_q_multi: activation planes too small");
   float* out[3] = {nullptr, nullptr, nullptr};
+  bool can_merge = on;
   for (int i = 0; i < n; ++i) {
     if (S[i] == 1) {
       out[i] = y[i];
     } else {
       const size_t floats = (size_t)S[i] * T * w[i].rows;
-      if (!defer || !defer[i] || !defer[i]->buf || defer[i]->cap_floats < floats) return 0;
-      out[i] = defer[i]->buf;
+      if (!defer || !defer[i] || !defer[i]->buf || defer[i]->cap_floats < floats) can_merge = false;
+      else out[i] = defer[i]->buf;
     }
+  }
+  if (!can_merge) {
+    if (!direct) return 0;  // (integer-plane route: every matrix keeps its own slice count, the caller's launches are the same)
+    // the direct route one matrix at a time, with the group's slice count: the same sums as the merged launch
+    for (int i = 0; i < n; ++i) {
+      t_group_slices = S[0];
+      const int rc1 = tl_launch_gemm_q(w[i], planes, plane_stride, y[i], nullptr, T, terms, s, defer ? defer[i] : nullptr);
+      t_group_slices = 0;
+      if (rc1) return rc1;
+    }
+    *merged = true;
+    return 0;
   }
   const __bf16* xp = static_cast<const __bf16*>(planes);
   int rc = 0;

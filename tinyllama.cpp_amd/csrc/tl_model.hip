@@ -1067,6 +1067,7 @@ static int ensure_prefill_ws(tl_model* m, bool all_logits) {
 // this rank's partial for the whole chunk into pf.xpart (rank 0 folds the residual in) and ONE all-reduce of T x hidden
 // floats per projection pair turns the partials into the new residual stream.
 static int prefill_embed(tl_model* m, const int* toks_dev, int T, hipStream_t s) {
+  m->pf.pend = {nullptr, 0, 0};  // (a chunk that failed half-way must not leave its pending projection to the next one)
   return tl_launch_dequant_gather(m->tok, toks_dev, T, m->pf.xb, s);
 }
 // RMSNorm of the residual stream -> activation planes; a projection still pending as K-split partials is added on the way
@@ -1116,9 +1117,10 @@ static int qkv_deferred(tl_model* m, LayerW& L, int T, hipStream_t s) {
   float* const y3[3] = {p.qb, p.kb, p.vb};
   GemmDefer* const d3[3] = {&p.dq, &p.dk, &p.dv};
   const int same = w3[2].type == w3[0].type ? 3 : 2;
-  if (defer && w3[1].type == w3[0].type) TL_TRY(tl_launch_gemm_q_multi(w3, same, p.planes, ps, y3, T, terms, s, d3, &merged));
+  GemmDefer* const* d3p = defer ? d3 : nullptr;
+  if (w3[1].type == w3[0].type) TL_TRY(tl_launch_gemm_q_multi(w3, same, p.planes, ps, y3, T, terms, s, d3p, &merged));
   if (merged) {
-    if (same == 2) TL_TRY(tl_launch_gemm_q(w3[2], p.planes, ps, p.vb, nullptr, T, terms, s, &p.dv));
+    if (same == 2) TL_TRY(tl_launch_gemm_q(w3[2], p.planes, ps, p.vb, nullptr, T, terms, s, defer ? &p.dv : nullptr));
     return 0;
   }
   TL_HIP(hipEventRecord(p.fork, s));
@@ -1177,7 +1179,8 @@ static int prefill_mlp_half(tl_model* m, int l, int T, hipStream_t s) {
   const QW w2[2] = {qw_view(L.q[TL_T_FFN_GATE]), qw_view(L.q[TL_T_FFN_UP])};
   float* const y2[2] = {p.gb, p.ub};
   GemmDefer* const d2[2] = {&dg, &du};
-  if (defer && w2[0].type == w2[1].type) TL_TRY(tl_launch_gemm_q_multi(w2, 2, p.planes, ps, y2, T, terms, s, d2, &merged));
+  GemmDefer* const* d2p = defer ? d2 : nullptr;
+  if (w2[0].type == w2[1].type) TL_TRY(tl_launch_gemm_q_multi(w2, 2, p.planes, ps, y2, T, terms, s, d2p, &merged));
   if (!merged) {
     TL_HIP(hipEventRecord(p.fork, s));
     TL_HIP(hipStreamWaitEvent(p.side, p.fork, 0));

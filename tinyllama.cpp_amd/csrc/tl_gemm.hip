@@ -1244,10 +1244,14 @@ int launch_gemm_ws(const QW& w, const __bf16* xp, size_t ps, float* y, const flo
 }
 
 // K slices of an integer-plane launch of `tiles` tiles
-static int qi_slices(int tiles, int nk_all) {
+// (workgroups wanted on the chip: one per CU up to 128 tokens, two beyond. Measured, whole steps: 64 / 128 sequences 7.79 /
+// 12.03 ms with one against 7.94 / 12.49 with two, a 128-token prefill 11.56 against 12.01 ms, but 512 tokens 35.4
+// against 34.8 ms)
+static int qi_slices(int tiles, int nk_all, int T) {
   int S = 1;
-  if (ksplit_enabled() && tiles < 2 * gemm_num_cus()) {
-    S = (2 * gemm_num_cus() + tiles - 1) / tiles;
+  const int want = (T <= 128 ? 1 : 2) * gemm_num_cus();
+  if (ksplit_enabled() && tiles < want) {
+    S = (want + tiles - 1) / tiles;
     if (S > 8) S = 8;
     if (S > nk_all / 12) S = nk_all / 12;
     if (S < 1) S = 1;
@@ -1296,7 +1300,7 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
   const int tpad = (int)tl_gemm_padded_tokens(T);
   const int tiles = mtiles * ntiles;
-  int S = qi_slices(tiles, w.cols / GB_K);  // split K as in launch_gemm_ws_bn
+  int S = qi_slices(tiles, w.cols / GB_K, T);  // split K as in launch_gemm_ws_bn
   float* part = nullptr;
   bool deferred = false;
   TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
@@ -1596,7 +1600,7 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
     for (int i = 0; i < n; ++i) tiles += (w[i].rows + 127) / 128 * ntiles;
     S[0] = S[1] = S[2] = qd_slices(tiles, w[0].cols / 64, gemm_num_cus());
   } else {
-    for (int i = 0; i < n; ++i) S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K);
+    for (int i = 0; i < n; ++i) S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K, T);
   }
   TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w[0].cols, "tl_launch_gemm_q_multi: activation planes too small");
   float* out[3] = {nullptr, nullptr, nullptr};

@@ -78,6 +78,13 @@ int tlh_session_generate_text(tlh_session* s, const char* prompt, size_t prompt_
                               float top_p, const char* system_prompt, size_t system_len, int apply_q_a_format, char* buf,
                               size_t cap, size_t* n_out);
 
+/* TinyLlamaSession::generate_batch on text (api.h:68-78, api.cpp:836-1142): prompt i = prompts[offsets[i] .. offsets[i+1]);
+ * the results come back concatenated in buf with their end offsets in out_offsets[n_prompts + 1] (out_offsets[0] = 0);
+ * *n_out = total bytes, of which at most cap were written. */
+int tlh_session_generate_batch_text(tlh_session* s, const char* prompts, const size_t* offsets, int n_prompts, int steps,
+                                    float temperature, int top_k, float top_p, const char* system_prompt, size_t system_len,
+                                    int apply_q_a_format, char* buf, size_t cap, size_t* out_offsets, size_t* n_out);
+
 /* ---- host-side sampler pieces (api.cpp:86-97, 126-216), exposed for parity tests; no GPU involved ---- */
 int tlh_apply_repetition_penalty(float* logits, int n, const int* generated, int n_generated, float penalty);
 /* candidate ids and renormalised probabilities the sampler draws from; *n_out <= cap entries written */

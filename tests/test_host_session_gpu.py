@@ -174,6 +174,16 @@ def test_session_generates_from_text(H, pkg, oracle, tmp_path):
             want_by_qa[qa] = [int(i) for i in (want[0] if isinstance(want, tuple) else want)]
             assert s.generate_text(prompt, 12, temperature=0.0, system_prompt=system, apply_q_a_format=qa) == \
                 o.decode(want_by_qa[qa], True), (family, qa)
+        # generate_batch on text: every prompt's text equals its single run's (greedy, no penalty on this path, api.cpp:993)
+        s.set_max_batch(3)
+        s.set_repetition_penalty(1.0)
+        batch_prompts = [prompt, prompt[:7], prompt + b" " + prompt]
+        texts = s.generate_batch_text(batch_prompts, 6, temperature=0.0, system_prompt=system)
+        for bp, text in zip(batch_prompts, texts):
+            assert text == s.generate_text(bp, 6, temperature=0.0, system_prompt=system), (family, bp)
+        with pytest.raises(H.TlHostError, match="exceeds maximum batch size"):
+            s.generate_batch_text([prompt] * 4, 2)
+        s.set_repetition_penalty(1.3)
         s.close()
         om.close()
         if family == "spm":

@@ -247,6 +247,29 @@ int tlh_session_generate_text(tlh_session* s, const char* prompt, size_t prompt_
   });
 }
 
+int tlh_session_generate_batch_text(tlh_session* s, const char* prompts, const size_t* offsets, int n_prompts, int steps,
+                                    float temperature, int top_k, float top_p, const char* system_prompt, size_t system_len,
+                                    int qa, char* buf, size_t cap, size_t* out_offsets, size_t* n_out) {
+  if (!s || !n_out || !out_offsets || n_prompts < 0 || (n_prompts > 0 && !offsets))
+    return fail("tlh_session_generate_batch_text: bad argument");
+  return guarded([&] {
+    std::vector<std::string> in((size_t)n_prompts);
+    for (int i = 0; i < n_prompts; ++i) {
+      if (offsets[i + 1] < offsets[i]) throw std::runtime_error("tlh_session_generate_batch_text: offsets must not decrease");
+      in[i] = str_arg(prompts ? prompts + offsets[i] : nullptr, offsets[i + 1] - offsets[i]);
+    }
+    const std::vector<std::string> out =
+        s->s->generate_batch(in, steps, temperature, top_k, top_p, str_arg(system_prompt, system_len), qa != 0);
+    std::string all;
+    out_offsets[0] = 0;
+    for (int i = 0; i < n_prompts; ++i) {
+      all += out[i];
+      out_offsets[i + 1] = all.size();
+    }
+    copy_bytes(all, buf, cap, n_out);
+  });
+}
+
 int tlh_apply_repetition_penalty(float* logits, int n, const int* generated, int n_generated, float penalty) {
   if (!logits || n < 0 || n_generated < 0 || (n_generated > 0 && !generated)) return fail("tlh_apply_repetition_penalty: bad argument");
   return guarded([&] {

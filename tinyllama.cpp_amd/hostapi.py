@@ -42,6 +42,8 @@ SIGNATURES = {
     "tlh_tokenizer_format_prompt": [_vp, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, _i, _vp, C.c_size_t, _vp],
     "tlh_session_generate_text": [_vp, C.c_char_p, C.c_size_t, _i, _f, _i, _f, C.c_char_p, C.c_size_t, _i, _vp,
                                   C.c_size_t, _vp],
+    "tlh_session_generate_batch_text": [_vp, C.c_char_p, _vp, _i, _i, _f, _i, _f, C.c_char_p, C.c_size_t, _i, _vp, C.c_size_t,
+                                        _vp, _vp],
     "tlh_apply_repetition_penalty": [_vp, _i, _vp, _i, _f],
     "tlh_sampling_distribution": [_vp, _i, _f, _i, _f, _vp, _vp, _i, _vp],
     "tlh_sample": [_vp, _i, _f, _i, _f, C.c_uint32, _vp],
@@ -219,6 +221,19 @@ class Session:
         return _bytes_out(lambda buf, cap, n: lib().tlh_session_generate_text(
             self.h, p, len(p), int(steps), float(temperature), int(top_k), float(top_p), s, len(s), int(apply_q_a_format),
             buf, cap, n), "tlh_session_generate_text", cap=4096 + 256 * max(int(steps), 0))
+
+    def generate_batch_text(self, prompts, steps=128, temperature=0.1, top_k=40, top_p=0.9, system_prompt=b"",
+                            apply_q_a_format=False):
+        """TinyLlamaSession::generate_batch as the reference declares it: texts in, texts (bytes) out."""
+        ps = [_b(p) for p in prompts]
+        flat, sysb = b"".join(ps), _b(system_prompt)
+        offs = (C.c_size_t * (len(ps) + 1))(*np.concatenate([[0], np.cumsum([len(p) for p in ps])]).astype(int).tolist())
+        outs = (C.c_size_t * (len(ps) + 1))()
+        raw = _bytes_out(lambda buf, cap, n: lib().tlh_session_generate_batch_text(
+            self.h, flat, offs, len(ps), int(steps), float(temperature), int(top_k), float(top_p), sysb, len(sysb),
+            int(apply_q_a_format), buf, cap, outs, n), "tlh_session_generate_batch_text",
+            cap=4096 + 256 * max(int(steps), 0) * max(len(ps), 1))
+        return [raw[outs[i]: outs[i + 1]] for i in range(len(ps))]
 
     def set_max_batch(self, n):
         check(lib().tlh_session_set_max_batch(self.h, int(n)), "tlh_session_set_max_batch")

@@ -16,6 +16,7 @@
 
 #include <type_traits>
 
+#include "tl_chunk.h"
 #include "tl_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -101,11 +102,20 @@ struct BatchAttnArgs {
 };
 
 // One workgroup per (kv head, token, head-group part): the G query heads of the group share every K/V row read.
-// A K/V row is read by HD/4 lanes x 16 B; U rows of K and of V per lane are in flight together and folded into a
-// running (max, sum, out) per lane group (online softmax), then the lane groups and the waves are folded.
+// A K/V row is read by 16 lanes (one DPP row) x 16 B x HD/64 loads, so the dot's reduction is four DPP adds (the first
+// version used HD/4 lanes per row and __shfl_xor, which is ds_bpermute on this target); U rows of K and of V per lane are
+// in flight together and folded into a running (max, sum, out) per lane group (online softmax), then the four lane
+// groups of a wave and the waves are folded.
+__device__ __forceinline__ float batch_row_sum16(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror
+  return v;
+}
 template <int HD, int G>
 __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a) {
-  constexpr int NW = 4, LP = HD / 4, PP = 64 / LP, U = 8, RECL = HD + 4;
+  constexpr int NW = 4, LP = 16, NV = HD / 64, PP = 64 / LP, U = 8 / NV, RECL = HD + 4;
   __shared__ __attribute__((aligned(16))) float part[NW * G * RECL];
   __shared__ float red[16];
   __shared__ __attribute__((aligned(16))) float outbuf[G * HD];
@@ -119,25 +129,31 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
   const int kv_dim = a.nkv * HD;
   const float* kbase = a.kc + (size_t)sq * a.seq_stride + (size_t)kvh * HD + 4 * ln;
   const float* vbase = a.vc + (size_t)sq * a.seq_stride + (size_t)kvh * HD + 4 * ln;
-  f32x4 qf[G], acc[G];
+  f32x4 qf[G][NV], acc[G][NV];
   float m[G], l[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    qf[g] = *reinterpret_cast<const f32x4*>(a.q + ((size_t)tok * a.nh + head0 + g) * HD + 4 * ln);
-    acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      qf[g][v] = *reinterpret_cast<const f32x4*>(a.q + ((size_t)tok * a.nh + head0 + g) * HD + 64 * v + 4 * ln);
+      acc[g][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     m[g] = -INFINITY;
     l[g] = 0.f;
   }
   for (int base = 0; base < len; base += NW * PP * U) {
-    f32x4 kk[U], vv[U];
+    f32x4 kk[U][NV], vv[U][NV];
     bool valid[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {  // unconditional, clamped loads: the whole batch in flight together
       const int idx = base + (u * NW + wave) * PP + sub;
       valid[u] = idx < len;
       const size_t off = (size_t)(valid[u] ? idx : len - 1) * kv_dim;
-      kk[u] = *reinterpret_cast<const f32x4*>(kbase + off);
-      vv[u] = *reinterpret_cast<const f32x4*>(vbase + off);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        kk[u][v] = *reinterpret_cast<const f32x4*>(kbase + off + 64 * v);
+        vv[u][v] = *reinterpret_cast<const f32x4*>(vbase + off + 64 * v);
+      }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -145,9 +161,11 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
       float mx = m[g];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        float d = (qf[g][0] * kk[u][0] + qf[g][1] * kk[u][1]) + (qf[g][2] * kk[u][2] + qf[g][3] * kk[u][3]);
+        float d = 0.f;
 #pragma unroll
-        for (int o = LP / 2; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+        for (int v = 0; v < NV; ++v)
+          d += (qf[g][v][0] * kk[u][v][0] + qf[g][v][1] * kk[u][v][1]) + (qf[g][v][2] * kk[u][v][2] + qf[g][v][3] * kk[u][v][3]);
+        d = batch_row_sum16(d);
         s[u] = valid[u] ? d * a.scale : -INFINITY;
         mx = fmaxf(mx, s[u]);
       }
@@ -155,15 +173,16 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
       const float corr = exp_diff(m[g], mx);
       m[g] = mx;
       l[g] *= corr;
-      acc[g][0] *= corr; acc[g][1] *= corr; acc[g][2] *= corr; acc[g][3] *= corr;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) acc[g][v] *= corr;
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const float p = valid[u] ? expf(s[u] - mx) : 0.f;
         l[g] += p;
-        acc[g][0] = fmaf(p, vv[u][0], acc[g][0]);
-        acc[g][1] = fmaf(p, vv[u][1], acc[g][1]);
-        acc[g][2] = fmaf(p, vv[u][2], acc[g][2]);
-        acc[g][3] = fmaf(p, vv[u][3], acc[g][3]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[g][v][e] = fmaf(p, vv[u][v][e], acc[g][v][e]);
       }
     }
   }
@@ -177,12 +196,15 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
       const float c = exp_diff(m[g], mn), co = exp_diff(mo, mn);
       l[g] = l[g] * c + __shfl_xor(l[g], o) * co;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[g][e] = acc[g][e] * c + __shfl_xor(acc[g][e], o) * co;
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[g][v][e] = acc[g][v][e] * c + __shfl_xor(acc[g][v][e], o) * co;
       m[g] = mn;
     }
     if (sub == 0) {
       float* rec = part + (size_t)(wave * G + g) * RECL;
-      *reinterpret_cast<f32x4*>(rec + 4 * ln) = acc[g];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(rec + 64 * v + 4 * ln) = acc[g][v];
       if (ln == 0) {
         rec[HD] = m[g];
         rec[HD + 1] = l[g];

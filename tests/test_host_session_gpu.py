@@ -141,15 +141,29 @@ def test_tl_run_binary(pkg, oracle, tmp_path):
 def test_session_generates_from_text(H, pkg, oracle, tmp_path):
     """TinyLlamaSession::generate as the reference declares it (text in, text out; api.cpp:488-835): the file's tokenizer
     formats and encodes the prompt, the ids run through the same loop as above, the generated ids are decoded without
-    special tokens. Word-level and SentencePiece-style vocabularies (tokenizer parity itself: tests/test_tokenizer_cpu.py,
-    unpinned); and tl_run --prompt."""
+    special tokens. Word-level, SentencePiece-style and Llama-3-style (recognised from the file's metadata, 128256 vocabulary
+    entries) vocabularies (tokenizer parity itself: tests/test_tokenizer_cpu.py, unpinned); and tl_run --prompt."""
     import test_tokenizer_cpu as TT
     from oracle import tokenizer_oracle as TO
     S = pkg.synth
     sp = TT.spm_parts()
-    for family in ("word", "spm"):
+    tk = TT.tiktoken_parts()
+    for family in ("word", "spm", "tiktoken"):
         cfg = dict(S.SHAPES["tiny"])
-        if family == "word":
+        if family == "tiktoken":
+            # Llama-3 as the reference recognises it (model_config.cpp:232): gpt2 + merges + 128256 vocabulary entries, which
+            # is also the model's vocabulary size; no template in the file -> the hard-coded Llama-3 instruct layout
+            V = 128256
+            fill = V - len(tk["tokens"])
+            tokens = tk["tokens"] + [b"[unused%d]" % i for i in range(fill)]
+            types = tk["token_types"] + [1] * fill
+            cfg["vocab"] = V
+            kvs = S.tokenizer_kvs(tokens, model="gpt2", merges=tk["merges"], token_types=types, bos=tk["bos"], eos=tk["eos"],
+                                  vocab_size=V)
+            o = TO.TokenizerOracle(TO.LLAMA3_TIKTOKEN, tokens, merges=tk["merges"], token_types=types, bos=tk["bos"],
+                                   eos=tk["eos"])
+            prompt, system, eos = b"what is the answer ?", b"be brief", tk["eos"]
+        elif family == "word":
             tokens = [b"<pad>", b"<unk>", b"<s>", b"</s>"] + [b"w%d" % i for i in range(4, cfg["vocab"])]
             kvs = S.tokenizer_kvs(tokens, model="word", bos=2, eos=3, unk=1, pad=0)
             o = TO.TokenizerOracle(TO.WORD_LEVEL, tokens, bos=2, eos=3, unk=1, pad=0)

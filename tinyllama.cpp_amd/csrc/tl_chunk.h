@@ -95,6 +95,17 @@ __device__ __forceinline__ void stg_f32(float* p, float v) {
 
 // ---- per-format: one 32-weight chunk in registers, its loads and its dot with 32 x ----------------------------
 // `base*` arguments are wave-uniform row bases, the per-lane part is a 32-bit byte offset
+// a * b - c and the Q6_K tail with the fusing fixed (contraction off around explicit fmaf): see Chunk<TL_Q4_K>::dot
+__device__ __forceinline__ float chunk_fms(float a, float b, float c) {
+#pragma clang fp contract(off)
+  return fmaf(a, b, -c);
+}
+__device__ __forceinline__ float chunk_q6_tail(float w0, float a0, float s0, float w1, float a1, float s1) {
+#pragma clang fp contract(off)
+  const float t0 = fmaf(-32.0f, s0, a0), t1 = fmaf(-32.0f, s1, a1);
+  return fmaf(w0, t0, w1 * t1);
+}
+
 template <int TYPE>
 struct Chunk;
 
@@ -135,7 +146,10 @@ struct Chunk<TL_Q4_K> {
     const float d = half_to_float(b[0] & 0xffffu), dmin = half_to_float(b[0] >> 16);
     const unsigned sc = ((b[1] >> (4 * j)) & 15u) | (((b[3] >> (2 * j)) & 3u) << 4);
     const unsigned mn = ((b[2] >> (4 * j)) & 15u) | (((b[3] >> (16 + 2 * j)) & 3u) << 4);
-    return (d * (float)sc) * q - (dmin * (float)mn) * (s0 + s1);
+    // ONE spelled-out fused form: left to the compiler, which of the two products is fused into the subtraction depends
+    // on the code around the inlined call, and kernels that must agree bit for bit (gemv_kernel's step schemes, the
+    // multi-vector GEMV) would differ in the last place
+    return chunk_fms(d * (float)sc, q, (dmin * (float)mn) * (s0 + s1));
   }
 };
 
@@ -171,7 +185,7 @@ struct Chunk<TL_Q6_K> {
     }
     const float df = half_to_float(d);
     const float sc0 = (float)(int)(signed char)(sc & 0xffu), sc1 = (float)(int)(signed char)((sc >> 8) & 0xffu);
-    return (df * sc0) * (acc[0] - 32.0f * s0) + (df * sc1) * (acc[1] - 32.0f * s1);
+    return chunk_q6_tail(df * sc0, acc[0], s0, df * sc1, acc[1], s1);  // (spelled-out fused form, see Chunk<TL_Q4_K>::dot)
   }
 };
 
@@ -194,7 +208,7 @@ struct ChunkQ8 {
       a0 = dot4(a[w] ^ 0x80808080u, x + 4 * w, a0);
       a1 = dot4(b[w] ^ 0x80808080u, x + 16 + 4 * w, a1);
     }
-    return scale_field(d) * ((a0 + a1) - 128.0f * (s0 + s1));
+    return scale_field(d) * chunk_fms(-128.0f, s0 + s1, -(a0 + a1));  // (a0 + a1) - 128 (s0 + s1), fused form spelled out
   }
 };
 template <>

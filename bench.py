@@ -59,6 +59,10 @@ def parse():
 # device; the shards are linked by the peer exchange only). A REHEARSAL of the control flow, not a measurement: the line
 # carries "rehearsal" and its numbers mean nothing.
 SHARE_GPU = os.environ.get("TL_BENCH_SHARE_GPU", "0") == "1"
+if SHARE_GPU and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # exchanges folded into GEMV launches wait for the same launch of the other ranks: on ONE device all ranks' launches
+    # have to fit on the chip together (csrc/tl_gemv.hip TL_GEMV_CUS); with a device per rank nothing is capped
+    os.environ.setdefault("TL_GEMV_CUS", str(max(1, 128 // int(os.environ["WORLD_SIZE"]))))
 
 
 def dist_setup(n_gpus):
@@ -142,15 +146,24 @@ def main():
                 # every rank then stays on RCCL.
                 import subprocess
                 import tempfile
-                box = [tempfile.mkdtemp(prefix="tl_peer_") if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                cmd = [sys.executable, "-u", os.path.join(ROOT, "tools", "peer_latency.py"), "--worker", str(tp_rank),
-                       str(tp_size), "--iters", "50", "--dir", box[0], "--device", str(local), "--rv-timeout", "30"]
-                try:
-                    pre_ok = subprocess.run(cmd, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
-                except Exception:
-                    pre_ok = False
-                linked = agree(pre_ok) and pkg_tp.peer_link(model, gather, agree)
+                # The children run the step in the form the bench would use: exchanges folded into the GEMV launches
+                # first, then (should that fail over real links) as launches of their own; TL_TP_PEER_FUSED pins one.
+                pinned = os.environ.get("TL_TP_PEER_FUSED")
+                linked = False
+                for mode in ([pinned] if pinned is not None else ["1", "0"]):
+                    box = [tempfile.mkdtemp(prefix="tl_peer_") if rank == 0 else None]
+                    dist.broadcast_object_list(box, src=0)
+                    cmd = [sys.executable, "-u", os.path.join(ROOT, "tools", "peer_latency.py"), "--worker", str(tp_rank),
+                           str(tp_size), "--iters", "50", "--dir", box[0], "--device", str(local), "--rv-timeout", "30"]
+                    try:
+                        pre_ok = subprocess.run(cmd, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                                env=dict(os.environ, TL_TP_PEER_FUSED=mode)).returncode == 0
+                    except Exception:
+                        pre_ok = False
+                    if agree(pre_ok):
+                        os.environ["TL_TP_PEER_FUSED"] = mode  # (read by tl_model_tp_peer_enable)
+                        linked = pkg_tp.peer_link(model, gather, agree)
+                        break
                 if SHARE_GPU and not linked:
                     raise RuntimeError("ranks sharing one GPU can only be linked by the peer exchange, which was refused: "
                                        + engine.lib().tl_last_error().decode(errors="replace"))
@@ -237,7 +250,8 @@ def main():
         kern[k] = {"us": round(us, 2), "gbps": round(nb / (us * 1e-6) / 1e9, 1)}
     if tp_world > 1:  # the step's all-reduce of f32[hidden], back to back on every rank (2 per layer in a step)
         us, nb = model.bench_kernel("tp_all_reduce", iters=500, warmup=50)
-        kern["tp_all_reduce"] = {"us": round(us, 2), "bytes": int(nb), "via": "peer" if model.tp_peer_enabled() else "rccl"}
+        kern["tp_all_reduce"] = {"us": round(us, 2), "bytes": int(nb), "as": "a launch of its own, back to back",
+                                 "via": ("peer-folded" if model.tp_peer_fused() else "peer") if model.tp_peer_enabled() else "rccl"}
     # whole eager steps with an event after every launch (includes ~5 us of event overhead per launch; the GEMV rows
     # above are the clean numbers): kept for the non-GEMV kernels
     prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
@@ -266,7 +280,7 @@ def main():
                                   if tp_fallback else
                                   f"tp{world}: row/column-split projections, 2 all-reduces of f32[{cfg['hidden']}] "
                                   f"per layer + logits all-gather "
-                                  f"({'one-shot peer-to-peer exchange kernels over xGMI (hipIpc-mapped areas)' if model.tp_peer_enabled() else 'RCCL'}), "
+                                  f"({('one-shot peer-to-peer exchange over xGMI (hipIpc-mapped areas) ' + ('inside the attn_output / ffn_down / lm_head launches' if model.tp_peer_fused() else 'as one kernel each')) if model.tp_peer_enabled() else 'RCCL'}), "
                                   f"{'inside the captured step graph' if model.graph_captured() else 'eager launches (capture refused)'}",
                    "weight_bytes_per_token_per_gpu": int(w_bytes), "kv_bytes_per_token_mid_per_gpu": int(kv_bytes)},
         # per GPU: every rank streams its own 1/N of the bytes in the same step time
@@ -289,6 +303,9 @@ def main():
         out["all_reduces_per_step"] = 0 if tp_fallback else 2 * cfg["n_layers"]
         out["exchange_us_per_step"] = None if tp_fallback or ar.get("us") is None else round(2 * cfg["n_layers"] * ar["us"], 1)
         out["graph_captured"] = bool(model.graph_captured())
+        fz = (not tp_fallback) and model.tp_peer_enabled() and model.tp_peer_fused()
+        out["launches_per_step"] = model.graph_nodes()  # (folded exchanges: the unsharded step's count)
+        out["exchange_launches_per_step"] = 0 if tp_fallback or fz else 2 * cfg["n_layers"] + 1
         out["weight_bytes_per_token_per_rank"] = int(w_bytes)
         out["kv_bytes_per_token_per_rank"] = int(kv_bytes)
     if SHARE_GPU and world > 1:

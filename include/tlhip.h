@@ -269,16 +269,25 @@ int tl_model_tp_init(tl_model* m, const void* unique_id_128);
  *   the host agrees on min(ok) over the ranks and calls tl_model_tp_peer_enable(m, agreed) on every rank.
  * Enabled: the decode step uses the peer kernels (the batched prefill's T x hidden all-reduces stay with RCCL and need
  * tl_model_tp_init; without a communicator a sharded prefill goes token by token). Every poll is bounded (5 s, or
- * TL_TP_PEER_TIMEOUT_MS): a missing rank turns into an error return of the decode / generate call, not a hang. */
+ * TL_TP_PEER_TIMEOUT_MS): a missing rank turns into an error return of the decode / generate call, not a hang.
+ * By default the exchanges are not even launches: the attn_output / ffn_down / lm_head GEMVs push their rows as they
+ * finish them and collect the other ranks' rows before they end, so the sharded step has exactly the launches of the
+ * unsharded one (tl_model_tp_peer_fused reports 1; TL_TP_PEER_FUSED=0 keeps one exchange kernel per all-reduce /
+ * all-gather). Folded exchanges wait inside full-chip launches: ranks that SHARE a device (rehearsals) must cap the
+ * launches so that all ranks fit together (TL_GEMV_CUS = CUs / ranks); with a device per rank nothing is needed. */
 int tl_model_tp_peer_export(tl_model* m, void* handle_out_64);
 int tl_model_tp_peer_import(tl_model* m, const void* handles_tp_x_64, int* ok_out);
 int tl_model_tp_peer_enable(tl_model* m, int on);
 int tl_model_tp_peer_enabled(const tl_model* m, int* on_out);
+int tl_model_tp_peer_fused(const tl_model* m, int* on_out);
 /* Diagnostic (no counterpart in the reference): *captured_out = 1 when the decode step replays as one hipGraph, 0 when
  * it is enqueued launch by launch (TL_NO_GRAPH=1, a shard without a communicator, or a collective that refused
  * capture). With TL_TP_SELFTEST=1 in the environment tl_model_tp_init gives a tp_size-1 model a one-rank communicator,
  * so the RCCL calls of the step and their capture can be exercised on one GPU. */
 int tl_model_graph_captured(const tl_model* m, int* captured_out);
+/* Diagnostic (no counterpart in the reference): the number of nodes (launches) of the captured decode step, 0 when the
+ * step is not captured. A tensor-parallel shard whose exchanges ride inside its GEMVs has as many as the whole model. */
+int tl_model_graph_nodes(const tl_model* m, int* nodes_out);
 /* Test hook: ALL n shards of a tp_size = n model live in this process on this device (created with tp_rank = 0..n-1,
  * finalized without tl_model_tp_init); one decode step in lockstep, collectives as plain kernels. */
 int tl_tp_local_group_decode(tl_model* const* shards, int n, int token_id, int pos, float* logits_host,

@@ -71,7 +71,7 @@ def main():
     ptoks = np.random.default_rng(3).integers(0, cfg["vocab"], 40).astype(np.int32)
     last = m.prefill(ptoks, 0)  # no communicator: token by token through the linked decode graph
     np.savez(os.path.join(workdir, f"result_{rank}.npz"), linked=True, logits=logits, ids=ids, last=last,
-             captured=m.graph_captured(), peer=m.tp_peer_enabled())
+             captured=m.graph_captured(), peer=m.tp_peer_enabled(), fused=m.tp_peer_fused(), nodes=m.graph_nodes())
     rv.agree(True)  # nobody unmaps its area while another rank may still be writing into it
     m.free()
     return 0

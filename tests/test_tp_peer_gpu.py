@@ -2,7 +2,11 @@
 processes share GPU 0, map each other's receive areas through hipIpc handles, pass the collective self-check and decode
 one sequence, every process replaying its own captured step graph. On one device the words cross between processes (and
 between the 8 L2s of the chip) instead of xGMI links; protocol, epochs, slot reuse, bounded polls and the wiring are the
-same code that bench.py --gpus N runs. Results vs the unsharded CPU oracle; all ranks must agree bit for bit."""
+same code that bench.py --gpus N runs. Results vs the unsharded CPU oracle; all ranks must agree bit for bit.
+Both forms of the exchange run: folded into the attn_output / ffn_down / lm_head launches (the default; the step then has
+exactly the launches of the unsharded step) and as launches of their own (TL_TP_PEER_FUSED=0). A folded exchange waits
+inside a GEMV launch for the same launch of the other ranks, so ranks that share ONE device cap their GEMV grids
+(TL_GEMV_CUS) to fit on the chip together; with a device per rank that is not needed."""
 import os
 import subprocess
 import sys
@@ -22,9 +26,22 @@ def close(a, b, tol):
     return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
 
 
-@pytest.mark.parametrize("shape,mix,tp", [("tiny-gqa", "q4_k_m", 2), ("tiny-tp", "q4_k_m", 4)])
-def test_peer_linked_processes_match_oracle(pkg, oracle, tmp_path, shape, mix, tp):
-    env = dict(os.environ, TL_TP_PEER_TIMEOUT_MS="4000")
+def _unsharded_nodes(pkg, shape, mix):
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    cfg, tensors = pkg.synth.build_model(shape, mix, seed=5)
+    m = E.Model(cfg)
+    m.load(tensors)
+    n = m.graph_nodes()
+    m.free()
+    return n
+
+
+@pytest.mark.parametrize("shape,mix,tp,fused", [("tiny-gqa", "q4_k_m", 2, 1), ("tiny-tp", "q4_k_m", 4, 1),
+                                                ("tiny-gqa", "q6_k", 2, 1), ("tiny-gqa", "q4_k_m", 2, 0),
+                                                ("tiny-tp", "q4_k_m", 4, 0)])
+def test_peer_linked_processes_match_oracle(pkg, oracle, tmp_path, shape, mix, tp, fused):
+    env = dict(os.environ, TL_TP_PEER_TIMEOUT_MS="4000", TL_TP_PEER_FUSED=str(fused), TL_GEMV_CUS=str(128 // tp))
     procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_tp_peer_worker.py"), str(r), str(tp), shape, mix,
                                str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(tp)]
@@ -40,7 +57,10 @@ def test_peer_linked_processes_match_oracle(pkg, oracle, tmp_path, shape, mix, t
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(f"rank {i} rc {p.returncode}\n{o}" for i, (p, o) in enumerate(zip(procs, outs)))
     res = [dict(np.load(os.path.join(tmp_path, f"result_{r}.npz"))) for r in range(tp)]
     for r in res:
-        assert bool(r["linked"]) and bool(r["peer"]) and bool(r["captured"])
+        assert bool(r["linked"]) and bool(r["peer"]) and bool(r["captured"]) and bool(r["fused"]) == bool(fused)
+    # folded: no launch is an exchange; as launches: 2 per layer + the logits gather on top of the unsharded step
+    extra = 0 if fused else 2 * pkg.synth.SHAPES[shape]["n_layers"] + 1
+    assert all(int(r["nodes"]) == _unsharded_nodes(pkg, shape, mix) + extra for r in res), [int(r["nodes"]) for r in res]
     cfg, tensors = pkg.synth.build_model(shape, mix, seed=5)
     om = OracleModel(oracle, cfg, tensors)
     toks = np.random.default_rng(2).integers(0, cfg["vocab"], 9).astype(np.int32)
@@ -64,7 +84,7 @@ def test_peer_linked_processes_match_oracle(pkg, oracle, tmp_path, shape, mix, t
 
 
 def _run_workers(tmp_path, tp, shape, mix, extra=(), env_extra=None):
-    env = dict(os.environ, TL_TP_PEER_TIMEOUT_MS="4000")
+    env = dict(os.environ, TL_TP_PEER_TIMEOUT_MS="4000", TL_GEMV_CUS=str(128 // tp))
     env.update(env_extra or {})
     procs = [subprocess.Popen([sys.executable, "-u", os.path.join(HERE, "_tp_peer_worker.py"), str(r), str(tp), shape, mix,
                                str(tmp_path), *extra], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

@@ -98,6 +98,8 @@ SIGNATURES = {
     "tl_model_tp_peer_import": [_vp, _vp, _vp],
     "tl_model_tp_peer_enable": [_vp, C.c_int],
     "tl_model_tp_peer_enabled": [_vp, _vp],
+    "tl_model_tp_peer_fused": [_vp, _vp],
+    "tl_model_graph_nodes": [_vp, _vp],
     "tl_tp_local_group_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
 }
 

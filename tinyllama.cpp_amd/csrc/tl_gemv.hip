@@ -47,6 +47,7 @@ struct GemvVec {
   // with separate scalar loads where first used: two more dependent round trips (~0.25 us each, cold scalar cache)
   // between kernel entry and a wave's first weight load
   int nthr, grid;
+  const TlPeerDev* peer;  // PEER instantiations only: the exchange this launch carries (tl_internal.h)
 };
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
@@ -236,6 +237,72 @@ __device__ __forceinline__ void group_of(const Segs& g, int rg, QW& wa, QW& wb, 
   rb = ra + 1 < wa.rows ? ra + 1 : wa.rows - 1;  // odd tail: computed twice, stored once
 }
 
+// ---- the exchange folded into the epilogue (PEER instantiations; protocol and reasons in tl_peer.hip) -----------------
+typedef unsigned long long pu64;
+typedef pu64 __attribute__((address_space(1))) * peer_gptr;
+__device__ __forceinline__ void peer_store(pu64* p, pu64 w) {
+  __hip_atomic_store((peer_gptr)(uintptr_t)p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ pu64 peer_load(const pu64* p) {
+  return __hip_atomic_load((peer_gptr)(uintptr_t)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// row `row` of this rank, value v, epoch e: one 8-byte word into slot [e & 1][rank][row] of every rank's area
+// (ALL: of this rank's own area too -- the all-reduce then reads every addend the same way)
+template <bool ALL>
+__device__ __forceinline__ void peer_push(const TlPeerDev* pd, unsigned e, int row, float v) {
+  const int tp = pd->tp, rank = pd->rank, n = pd->n;
+  const size_t at = ((size_t)(e & 1u) * (size_t)tp + (size_t)rank) * (size_t)n + (size_t)row;
+  const pu64 w = ((pu64)e << 32) | (pu64)__float_as_uint(v);
+#pragma unroll
+  for (int p = 0; p < TL_PEER_MAX_RANKS; ++p)
+    if (p < tp && (ALL || p != rank)) peer_store(pd->rx[p] + at, w);
+}
+// The wave's own rows again (row groups first, first + stride, ... of a single-matrix launch: rows 2 rg and 2 rg + 1), one
+// row per lane, 32 row groups per pass: wait for every rank's word of the row (bounded by the deadline), then
+// REDUCE: out[row] = sum in rank order 0 .. tp-1 (every rank computes the same bits); else: out[(q - rank) n + row] = rank
+// q's value for q != rank (out points at this rank's rows of the gathered vector).
+template <bool REDUCE>
+__device__ __forceinline__ void peer_collect(const TlPeerDev* pd, unsigned e, float* out, int rows, int first, int stride,
+                                             int total, int lane) {
+  const int tp = pd->tp, rank = pd->rank, n = pd->n;
+  const pu64* mine = pd->rx[0];
+#pragma unroll
+  for (int q = 1; q < TL_PEER_MAX_RANKS; ++q) mine = q == rank ? pd->rx[q] : mine;
+  mine += (size_t)(e & 1u) * (size_t)tp * (size_t)n;
+  const pu64 deadline = __builtin_amdgcn_s_memrealtime() + pd->timeout_ticks;
+  bool ok = true;
+  for (int base = first; base < total; base += 32 * stride) {
+    const int rg = base + (lane >> 1) * stride;
+    const int row = 2 * rg + (lane & 1);
+    if (rg < total && row < rows) {
+      const pu64* at = mine + row;
+      pu64 w[TL_PEER_MAX_RANKS];
+#pragma unroll
+      for (int q = 0; q < TL_PEER_MAX_RANKS; ++q)  // the first round of polls of all ranks in flight together
+        w[q] = (q < tp && (REDUCE || q != rank)) ? peer_load(at + (size_t)q * n) : 0ull;
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < TL_PEER_MAX_RANKS; ++q) {
+        if (q >= tp || (!REDUCE && q == rank)) continue;
+        pu64 x = w[q];
+        for (unsigned it = 1; (unsigned)(x >> 32) != e; ++it) {
+          if ((it & 63u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) {
+            ok = false;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+          x = peer_load(at + (size_t)q * n);
+        }
+        const float v = __uint_as_float((unsigned)x);
+        if (REDUCE) acc += v;
+        else stg_f32(out + ((long)(q - rank) * n + row), v);
+      }
+      if (REDUCE) stg_f32(out + row, acc);
+    }
+  }
+  if (!ok) atomicOr(pd->err, 1u);
+}
+
 template <int TYPE>
 struct Step {
   Chunk<TYPE> c0, c1;
@@ -255,9 +322,9 @@ struct StepMeta {
 // vmcnt that leaves the prefetch in flight.
 // RESID: out[r] = resid[r] + y[r]. The two residual values are loaded at ISSUE time, ahead of the step's weight loads:
 // loads complete in order, so a load in the epilogue would drain the whole prefetch queue once per row group.
-template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP>
+template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP, bool PEER = false>
 __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const XRegs& xr, float* smem, int first,
-                                          int stride, int total, int lane, unsigned long long* ts) {
+                                          int stride, int total, int lane, unsigned long long* ts, unsigned pe = 0) {
   const float* xs = smem + XS_SCRATCH;
   const int nchunks = a.cols >> 5;
   const int nspans = (nchunks + 63) >> 6;
@@ -316,6 +383,13 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
         if (PAIR) {
           const float sg = 1.0f / (1.0f + expf(-y0));  // silu_cpu (utils.cpp:700-707), then * up (model.cpp:735)
           stg_f32(m.out + m.ra, (y0 * sg) * y1);
+        } else if (PEER) {  // the rows leave for the other ranks the moment they exist; collected below
+          peer_push<RESID>(a.peer, pe, m.ra, RESID ? st.r0 + y0 : y0);
+          if (m.ra + 1 < m.rows) peer_push<RESID>(a.peer, pe, m.ra + 1, RESID ? st.r1 + y1 : y1);
+          if (!RESID) {
+            stg_f32(m.out + m.ra, y0);
+            if (m.ra + 1 < m.rows) stg_f32(m.out + m.ra + 1, y1);
+          }
         } else {
           stg_f32(m.out + m.ra, RESID ? st.r0 + y0 : y0);
           if (m.ra + 1 < m.rows) stg_f32(m.out + m.ra + 1, RESID ? st.r1 + y1 : y1);
@@ -348,6 +422,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   if (STAMP) ts[6] = __builtin_readcyclecounter();  // every load of this wave has been issued
   consume(cur, mc);
   if (STAMP && ts[5] == 0) ts[5] = __builtin_readcyclecounter();
+  if (PEER) peer_collect<RESID>(a.peer, pe, g.o0, g.w0.rows, first, stride, total, lane);
 }
 
 
@@ -519,7 +594,9 @@ __device__ __forceinline__ void run_class_flat(const Segs& g, const GemvVec& a, 
 // Waves [0, wavesA) of every workgroup run class A, the others class B.
 // ROLE only names the instantiation (tl_internal.h GemvRole) so that profiles separate the per-layer launches.
 // RA > 0: the flattened step scheme above with RA rows per stream and group (the host sizes t0..t2 accordingly).
-template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0>
+// PEER: the launch carries its tensor-parallel exchange (a.peer; single matrix, RA = 0): all-reduce for the residual roles,
+// all-gather otherwise.
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false>
 __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
                                                                 int t0, int t1, int t2, int nsegA, int wavesA) {
   // the roles launched with a residual / with x still in attention partials
@@ -551,6 +628,11 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
   XRegs xr;
   stage_x_issue<XATTN>(a, xr);
   if (STAMP) ts[2] = __builtin_readcyclecounter();
+  unsigned pe = 0;  // the epoch this launch's words carry: one more than the exchanges completed (0 = cleared area)
+  if (PEER) {
+    pe = __hip_atomic_load(a.peer->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    pe = __builtin_amdgcn_readfirstlane(pe == 0u ? 1u : pe);
+  }
   if (TB == TL_NONE || wave < wavesA) {
     const int wA = TB == TL_NONE ? nwaves : wavesA;
     const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
@@ -558,7 +640,8 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
     if constexpr (RA > 0)
       run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane);
     else
-      run_class<TA, PAIR, RESID, XATTN, STAMP>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane, ts);
+      run_class<TA, PAIR, RESID, XATTN, STAMP, PEER>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane,
+                                                     ts, pe);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
@@ -570,6 +653,16 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
     else
       run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * a.grid + blockIdx.x,
                                                  a.grid * (nwaves - wavesA), tb, lane, ts);
+  }
+  if (PEER) {  // every wave has read the epoch and collected its rows: the last workgroup through advances the epoch
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned before = __hip_atomic_fetch_add(a.peer->done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (before == (unsigned)a.grid - 1u) {
+        __hip_atomic_store(a.peer->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.peer->epoch, pe, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
   if (STAMP && lane == 0 && ts[5] != 0) {
     ts[7] = __builtin_readcyclecounter();
@@ -598,9 +691,19 @@ static int g_gemv_setup_done = 0;
 static int g_num_cus = 256;
 static int g_max_waves = 16;
 
+// TL_GEMV_CUS: at most this many workgroups per GEMV launch. For rehearsals of tensor parallelism with several ranks on
+// ONE device: a launch that carries its exchange waits for the same launch of the other ranks, so all of them have to fit
+// on the chip together (ranks x cap <= CUs); on a device per rank the question does not arise.
+static int g_cu_cap = 0;
 static int gemv_setup() {
   g_num_cus = tl_num_cus();  // of the CURRENT device (cached per ordinal): a process may drive unlike devices
+  if (g_cu_cap > 0 && g_num_cus > g_cu_cap) g_num_cus = g_cu_cap;
   if (g_gemv_setup_done) return 0;
+  if (const char* e = getenv("TL_GEMV_CUS")) {
+    const int c = atoi(e);
+    if (c >= 1) g_cu_cap = c;
+    if (g_cu_cap > 0 && g_num_cus > g_cu_cap) g_num_cus = g_cu_cap;
+  }
   if (const char* e = getenv("TL_GEMV_WAVES")) {  // tuning knob (experiments only)
     const int w = atoi(e);
     if (w >= 1 && w <= 16) g_max_waves = w;
@@ -619,19 +722,23 @@ struct Launch {
   int ra;  // 0: span steps; 2 / 4: flattened steps with that many rows per stream and group
 };
 
-template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0>
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false>
 static int gemv_launch_ra(const Launch& L, hipStream_t s) {
   static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
-  TL_TRY(tl_raise_lds_limit(gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA>, 160 * 1024, lds_raised));
+  TL_TRY(tl_raise_lds_limit(gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA, PEER>, 160 * 1024, lds_raised));
   GemvVec v = L.v;
   v.nthr = L.threads;
   v.grid = L.grid;
-  gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], v, L.t[0],
-                                                                               L.t[1], L.t[2], L.nsegA, L.wavesA);
+  gemv_kernel<TA, TB, PAIR, ROLE, STAMP, RA, PEER><<<L.grid, L.threads, L.lds, s>>>(L.seg[0], L.seg[1], L.seg[2], v, L.t[0],
+                                                                                     L.t[1], L.t[2], L.nsegA, L.wavesA);
   return 0;
 }
 template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false>
 static int gemv_launch_one(const Launch& L, hipStream_t s) {
+  if constexpr (!STAMP && !PAIR && TB == TL_NONE &&
+                (ROLE == GEMV_ATTN_OUT || ROLE == GEMV_DOWN || ROLE == GEMV_ATTN_OUT_COMBINE || ROLE == GEMV_LM_HEAD)) {
+    if (L.v.peer) return gemv_launch_ra<TA, TB, PAIR, ROLE, false, 0, true>(L, s);  // (the host keeps these on spans)
+  }
   if constexpr (!STAMP && TA != TL_Q8_K) {  // (the host never picks the flattened scheme for Q8_K or the stamped run)
     if (L.ra == 2) return gemv_launch_ra<TA, TB, PAIR, ROLE, false, 2>(L, s);
   }
@@ -721,7 +828,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   bool any_f32 = false;
   for (int i = 0; i < a.nseg; ++i) any_f32 |= a.seg[i].w.type == TL_F32;
   if (any_f32) {
-    TL_REQUIRE(!a.pair && !a.norm_w, "gemv: F32 matrices are not supported in fused launches");
+    TL_REQUIRE(!a.pair && !a.norm_w && !a.peer, "gemv: F32 matrices are not supported in fused launches");
     for (int i = 0; i < a.nseg; ++i) {
       TL_REQUIRE(a.seg[i].w.type == TL_F32, "gemv: mixed F32 / quantized segments are not supported");
       const QW& w = a.seg[i].w;
@@ -734,14 +841,17 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
-  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged, 0, 0};
+  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged, 0, 0, a.peer};
+  if (a.peer)
+    TL_REQUIRE(a.nseg == 1 && !a.pair && (a.resid || a.role == GEMV_LM_HEAD),
+               "gemv: a launch that carries its exchange is one matrix with a residual (all-reduce) or the lm_head (all-gather)");
   for (int i = 0; i < 3; ++i) L.seg[i] = a.seg[i < a.nseg ? i : 0];
   const int ta = a.seg[0].w.type;
   bool flat_ok = true;
   for (int i = 0; i < a.nseg; ++i) flat_ok &= a.seg[i].w.type != TL_Q8_K;
   long total_rows = 0;
   for (int i = 0; i < (a.pair ? 1 : a.nseg); ++i) total_rows += a.seg[i].w.rows;
-  L.ra = gemv_flat_rows(a.cols, flat_ok, total_rows, a.pair != 0);
+  L.ra = a.peer ? 0 : gemv_flat_rows(a.cols, flat_ok, total_rows, a.pair != 0);  // (the collect phase walks span row groups)
 
   if (a.pair) {
     if (a.seg[1].w.type != ta) {
@@ -844,7 +954,7 @@ extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, flo
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(w->cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "tl_debug_gemv_stamps: cols %d too large", w->cols);
-  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0, 0, 0, 0};
+  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0, 0, 0, 0, nullptr};
   for (int i = 0; i < 3; ++i) L.seg[i] = GemvSeg{qw_view(w), y_dev};
   L.t[0] = (w->rows + 1) / 2;
   L.nsegA = 1;

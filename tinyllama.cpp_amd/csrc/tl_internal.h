@@ -112,6 +112,18 @@ int tl_qweight_build(int type, const void* host_blocks, int rows, int cols, tl_q
 // ---- launchers shared between the operator-level C-ABI and the model engine ---------------------------
 // GEMV over 1..3 matrices that share the input vector (q|k|v in one launch), with optional fused
 // RMSNorm prologue, residual epilogue, or gate/up SwiGLU pairing; see tl_gemv.hip
+// One kind of exchange folded into a GEMV's epilogue (tl_peer.hip owns the object, in device memory; tl_gemv.hip's PEER
+// instantiations read it): the words of a row go out to every rank as soon as the row is reduced, and the wave that
+// pushed them polls this rank's own area for the same rows of the others before it ends. See tl_peer.hip.
+constexpr int TL_PEER_MAX_RANKS = 8;
+struct TlPeerDev {
+  unsigned long long* rx[TL_PEER_MAX_RANKS];  // every rank's receive area of this kind as mapped here: u64 [2 slots][tp][n]
+  unsigned* epoch;                            // exchanges of this kind completed on this rank (the words carry epoch + 1)
+  unsigned* done;                             // workgroups of the running launch that are through (the last one advances epoch)
+  unsigned* err;                              // sticky: a poll gave up at its deadline
+  unsigned long long timeout_ticks;           // of the 100 MHz realtime counter
+  int tp, rank, n;
+};
 enum GemvRole { GEMV_GENERIC = 0, GEMV_QKV, GEMV_ATTN_OUT, GEMV_GATE_UP, GEMV_DOWN, GEMV_LM_HEAD, GEMV_ATTN_OUT_COMBINE };
 struct GemvSeg {
   QW w;
@@ -133,6 +145,10 @@ struct GemvArgs {
   int attn_hd;
   int attn_merged;      // 1: the split kernel ran with AttnArgs::done_cnt (one record per head from TL_ATTN_MERGE_MIN splits on)
   int role;             // GemvRole: selects a separately named instantiation (profiling only)
+  // != NULL (tensor parallelism, single quantized segment): the exchange is part of this launch. With resid (row-split
+  // projection): out[r] = sum over ranks, in rank order, of (resid[r] + y[r]) -- an all-reduce; without (lm_head): this
+  // rank's rows go to out[r] and rank q's rows to out[(q - rank) * n + r] -- an all-gather in place.
+  const TlPeerDev* peer;
 };
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
 int tl_launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t s);
@@ -255,7 +271,6 @@ int tl_launch_argmax(float* logits, int n, int* result_dev, const int* hist, con
 // ---- tl_peer.hip: one-shot peer-to-peer exchange for the tensor-parallel decode step (hipIpc-mapped receive areas,
 //      8-byte {value, epoch} words, bounded polls). tl_peer_create makes this rank's area and its 64-byte IPC handle;
 //      tl_peer_connect takes the handles of all tp ranks (rank order); tl_peer_selftest is collective.
-constexpr int TL_PEER_MAX_RANKS = 8;
 struct TlPeer;
 int tl_peer_create(int tp, int rank, int n_reduce, int n_gather, TlPeer** out, void* handle_out_64);
 int tl_peer_connect(TlPeer* p, const void* handles);
@@ -265,6 +280,10 @@ int tl_peer_all_gather(TlPeer* p, float* buf, hipStream_t s);
 int tl_peer_error_async(TlPeer* p, unsigned* flag_host, hipStream_t s);
 int tl_peer_clear_error(TlPeer* p, hipStream_t s);  // the flag is sticky until cleared
 void tl_peer_destroy(TlPeer* p);
+// the device-side descriptions of the exchanges that a GEMV launch carries itself (GemvArgs::peer); valid after connect.
+// They have areas and epochs of their own: launches of tl_peer_all_reduce / all_gather may be mixed in freely.
+const TlPeerDev* tl_peer_fused_reduce(TlPeer* p);
+const TlPeerDev* tl_peer_fused_gather(TlPeer* p);
 
 // ---- tl_batch.hip: position-dependent kernels of the multi-sequence decode step (sequence-major KV cache) ------------
 int tl_launch_batch_rope_kv(float* q, float* k, const float* v, float* kc, float* vc, size_t seq_stride, const float* table,

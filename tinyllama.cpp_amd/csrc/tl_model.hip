@@ -52,6 +52,10 @@ struct tl_model {
   // all-gather, used instead of the RCCL calls once every rank's self-check passed (tl_model_tp_peer_enable)
   TlPeer* peer = nullptr;
   bool peer_on = false;
+  // peer_on: the exchanges ride in the epilogues of the launches that produce their inputs (attn_output, ffn_down, lm_head;
+  // tl_gemv.hip PEER) instead of launches of their own; TL_TP_PEER_FUSED=0 keeps the exchange launches (A/B, fallback)
+  bool peer_fused = true;
+  bool fused(const tl_qweight* w) const { return peer_on && peer_fused && w->type != TL_F32; }
   bool linked() const { return comm != nullptr || peer_on; }  // this shard can exchange with the rest of its group
   std::vector<LayerW> layers;
   tl_qweight* tok = nullptr;
@@ -450,9 +454,12 @@ static GemvArgs args_qkv(tl_model* m, int l) {
 }
 // tp > 1: the row-split projections (attn_output, ffn_down) write this rank's PARTIAL sum into xp; rank 0 folds the
 // residual into its partial, so that the all-reduce (sum) of the partials is the new residual stream on every rank.
+// With the exchange folded into the launch (tl_model::fused) the sum over ranks lands in x directly.
 static GemvArgs args_attn_out(tl_model* m, int l) {
   GemvArgs o = {};
-  o.seg[0] = {qw_view(m->layers[l].q[TL_T_ATTN_OUTPUT]), m->tp > 1 ? m->xp : m->x};
+  const bool fz = m->fused(m->layers[l].q[TL_T_ATTN_OUTPUT]);
+  o.seg[0] = {qw_view(m->layers[l].q[TL_T_ATTN_OUTPUT]), m->tp > 1 && !fz ? m->xp : m->x};
+  o.peer = fz ? tl_peer_fused_reduce(m->peer) : nullptr;
   o.nseg = 1;
   o.cols = m->qd_l;
   o.x = m->att;
@@ -482,7 +489,9 @@ static GemvArgs args_gate_up(tl_model* m, int l) {
 }
 static GemvArgs args_down(tl_model* m, int l) {
   GemvArgs d = {};
-  d.seg[0] = {qw_view(m->layers[l].q[TL_T_FFN_DOWN]), m->tp > 1 ? m->xp : m->x};
+  const bool fz = m->fused(m->layers[l].q[TL_T_FFN_DOWN]);
+  d.seg[0] = {qw_view(m->layers[l].q[TL_T_FFN_DOWN]), m->tp > 1 && !fz ? m->xp : m->x};
+  d.peer = fz ? tl_peer_fused_reduce(m->peer) : nullptr;
   d.nseg = 1;
   d.cols = m->I_l;
   d.x = m->h;
@@ -499,6 +508,7 @@ static GemvArgs args_lm_head(tl_model* m) {
   f.norm_w = m->out_norm;
   f.eps = m->cfg.rms_norm_eps;
   f.role = GEMV_LM_HEAD;
+  f.peer = m->fused(m->out) ? tl_peer_fused_gather(m->peer) : nullptr;
   return f;
 }
 
@@ -549,8 +559,10 @@ static int launch_proj(tl_model* m, const GemvArgs& a, hipStream_t s) {
   } while (0)
 
 // x = sum over ranks of xp (RCCL over xGMI; one f32[hidden_size] all-reduce per row-split projection)
-static int tp_all_reduce(tl_model* m, hipStream_t s) {
+// (w: the row-split matrix whose launch produced xp; when that launch carried the exchange itself there is nothing to do)
+static int tp_all_reduce(tl_model* m, hipStream_t s, const tl_qweight* w = nullptr) {
   if (m->tp == 1 && !m->comm) return 0;
+  if (w && m->fused(w)) return 0;
   if (m->peer_on) return tl_peer_all_reduce(m->peer, m->xp, m->x, s);
   TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
   // (tp == 1 with a communicator is the one-rank self-test of tl_model_tp_init: in place on x)
@@ -561,6 +573,7 @@ static int tp_all_reduce(tl_model* m, hipStream_t s) {
 // every rank gets the full logits (in place: its own vocabulary rows already sit at rank * V_l) and samples
 static int tp_gather_logits(tl_model* m, hipStream_t s) {
   if (m->tp == 1 && !m->comm) return 0;
+  if (m->fused(m->out)) return 0;  // the lm_head launch gathered
   if (m->peer_on) return tl_peer_all_gather(m->peer, m->logits, s);
   TL_REQUIRE(m->comm, "tl_model: tp_size %d but tl_model_tp_init was not called", m->tp);
   TL_NCCL(ncclAllGather(m->logits + (size_t)m->rank * m->V_l, m->logits, (size_t)m->V_l, ncclFloat, m->comm, s));
@@ -651,10 +664,10 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr, bool sampled = fa
   PROF_MARK(0);
   for (int l = 0; l < m->cfg.num_hidden_layers; ++l) {
     TL_TRY(enqueue_attn_half(m, l, s, prof));
-    TL_TRY(tp_all_reduce(m, s));
+    TL_TRY(tp_all_reduce(m, s, m->layers[l].q[TL_T_ATTN_OUTPUT]));
     PROF_MARK(4);
     TL_TRY(enqueue_mlp_half(m, l, s, prof));
-    TL_TRY(tp_all_reduce(m, s));
+    TL_TRY(tp_all_reduce(m, s, m->layers[l].q[TL_T_FFN_DOWN]));
     PROF_MARK(6);
   }
   TL_TRY(enqueue_head(m, s));
@@ -778,13 +791,16 @@ extern "C" int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmu
   }
   auto args_of = [&](int i) {
     const int l = i % L;
+    GemvArgs a;
     switch (kind) {
-      case 1: return args_qkv(m, l);
-      case 4: return args_attn_out(m, l);
-      case 5: return args_gate_up(m, l);
-      case 6: return args_down(m, l);
-      default: return args_lm_head(m);
+      case 1: a = args_qkv(m, l); break;
+      case 4: a = args_attn_out(m, l); break;
+      case 5: a = args_gate_up(m, l); break;
+      case 6: a = args_down(m, l); break;
+      default: a = args_lm_head(m); break;
     }
+    a.peer = nullptr;  // the timed launch alone: not a collective of the group
+    return a;
   };
   double bytes = 0.0;
   for (int i = 0; i < iters; ++i) {
@@ -1771,6 +1787,16 @@ extern "C" int tl_model_graph_captured(const tl_model* m, int* captured_out) {
   return 0;
 }
 
+extern "C" int tl_model_graph_nodes(const tl_model* m, int* nodes_out) {
+  TL_REQUIRE(m && m->finalized && nodes_out, "tl_model_graph_nodes: bad argument");
+  *nodes_out = 0;
+  if (!m->graph || m->no_graph) return 0;
+  size_t n = 0;
+  TL_HIP(hipGraphGetNodes(m->graph, nullptr, &n));
+  *nodes_out = (int)n;
+  return 0;
+}
+
 extern "C" int tl_tp_unique_id(void* id_out_128) {
   TL_REQUIRE(id_out_128, "tl_tp_unique_id: null argument");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
@@ -1813,6 +1839,12 @@ extern "C" int tl_model_tp_peer_enable(tl_model* m, int on) {
   TL_REQUIRE(m && !m->finalized, "tl_model_tp_peer_enable: call before tl_model_finalize");
   TL_REQUIRE(!on || m->peer, "tl_model_tp_peer_enable: nothing imported");
   m->peer_on = on != 0;
+  if (const char* e = getenv("TL_TP_PEER_FUSED")) m->peer_fused = atoi(e) != 0;
+  return 0;
+}
+extern "C" int tl_model_tp_peer_fused(const tl_model* m, int* on_out) {
+  TL_REQUIRE(m && on_out, "tl_model_tp_peer_fused: null argument");
+  *on_out = m->peer_on && m->peer_fused ? 1 : 0;
   return 0;
 }
 extern "C" int tl_model_tp_peer_enabled(const tl_model* m, int* on_out) {

@@ -16,6 +16,12 @@
 //     uncached allocations, so neither the writer's nor the reader's L2 (8 per GPU) ever holds a stale word;
 //   - every poll is bounded by a wall-clock deadline: a missing peer raises an error flag, never a hung GPU.
 // The kernels are plain launches: they are captured into the per-rank step graph like every other kernel of the step.
+// Folded form: the same protocol carried by the GEMV launches on the producing side of an exchange
+// (tl_gemv.hip, PEER instantiations; the object they read is TlPeerDev): the lane that holds a finished row pushes its
+// word to every rank, and at the end of its work the wave polls this rank's area for its own rows of all ranks, sums them
+// in rank order (row-split projections) or files them (lm_head) and writes the result where the next launch reads it: no
+// exchange launch at all, 2 x layers + 1 fewer launches per token. These exchanges have areas and epochs of their own
+// (one epoch word per kind, advanced by the last workgroup of a launch), so both forms can be used side by side.
 // No counterpart in the reference (its multi-GPU story is a mock MPI coordinator).
 #include <hip/hip_runtime.h>
 
@@ -113,6 +119,9 @@ struct TlPeer {
   unsigned* err = nullptr;
   u64 timeout_ticks = 0;
   bool connected = false;
+  // folded form: area sections 3 and 4 (same shapes as 1 and 2), {epoch, done} words per kind, device descriptions
+  unsigned* fused_words = nullptr;     // [0,1] reduce epoch / done, [2,3] gather epoch / done
+  TlPeerDev* fused_dev = nullptr;      // [0] reduce, [1] gather
 };
 
 static int peer_blocks(int n) { return (n + PEER_THREADS - 1) / PEER_THREADS; }
@@ -124,6 +133,8 @@ void tl_peer_destroy(TlPeer* p) {
   (void)hipFree(p->ctr_reduce);
   (void)hipFree(p->ctr_gather);
   (void)hipFree(p->err);
+  (void)hipFree(p->fused_words);
+  (void)hipFree(p->fused_dev);
   (void)hipFree(p->area);
   delete p;
 }
@@ -140,7 +151,7 @@ int tl_peer_create(int tp, int rank, int n_reduce, int n_gather, TlPeer** out, v
   p->n_reduce = n_reduce;
   p->n_gather = n_gather;
   p->mapped.assign(tp, nullptr);
-  p->area_words = 2 * (size_t)tp * ((size_t)n_reduce + (size_t)n_gather);
+  p->area_words = 2 * 2 * (size_t)tp * ((size_t)n_reduce + (size_t)n_gather);  // (launch form + folded form)
   double timeout_ms = 5000.0;
   if (const char* e = getenv("TL_TP_PEER_TIMEOUT_MS")) {
     const double v = atof(e);
@@ -161,6 +172,9 @@ int tl_peer_create(int tp, int rank, int n_reduce, int n_gather, TlPeer** out, v
   if ((e = hipMemset(p->ctr_reduce, 0, sizeof(unsigned) * peer_blocks(n_reduce))) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMemset(p->ctr_gather, 0, sizeof(unsigned) * peer_blocks(n_gather))) != hipSuccess) return fail("hipMemset", e);
   if ((e = hipMemset(p->err, 0, sizeof(unsigned))) != hipSuccess) return fail("hipMemset", e);
+  if ((e = hipMalloc(&p->fused_words, sizeof(unsigned) * 4)) != hipSuccess) return fail("hipMalloc", e);
+  if ((e = hipMemset(p->fused_words, 0, sizeof(unsigned) * 4)) != hipSuccess) return fail("hipMemset", e);
+  if ((e = hipMalloc(&p->fused_dev, sizeof(TlPeerDev) * 2)) != hipSuccess) return fail("hipMalloc", e);
   if ((e = hipDeviceSynchronize()) != hipSuccess) return fail("hipDeviceSynchronize", e);
   hipIpcMemHandle_t h;
   if ((e = hipIpcGetMemHandle(&h, p->area)) != hipSuccess) return fail("hipIpcGetMemHandle", e);
@@ -191,9 +205,28 @@ int tl_peer_connect(TlPeer* p, const void* handles) {
     p->rx_reduce.p[q] = base;
     p->rx_gather.p[q] = base + 2 * (size_t)p->tp * (size_t)p->n_reduce;
   }
+  TlPeerDev d[2] = {};
+  const size_t half = 2 * (size_t)p->tp * ((size_t)p->n_reduce + (size_t)p->n_gather);
+  for (int q = 0; q < TL_PEER_MAX_RANKS; ++q) {
+    d[0].rx[q] = p->rx_reduce.p[q] + half;
+    d[1].rx[q] = p->rx_gather.p[q] + half;
+  }
+  for (int k = 0; k < 2; ++k) {
+    d[k].epoch = p->fused_words + 2 * k;
+    d[k].done = p->fused_words + 2 * k + 1;
+    d[k].err = p->err;
+    d[k].timeout_ticks = p->timeout_ticks;
+    d[k].tp = p->tp;
+    d[k].rank = p->rank;
+    d[k].n = k == 0 ? p->n_reduce : p->n_gather;
+  }
+  TL_HIP(hipMemcpy(p->fused_dev, d, sizeof(d), hipMemcpyHostToDevice));
   p->connected = true;
   return 0;
 }
+
+const TlPeerDev* tl_peer_fused_reduce(TlPeer* p) { return p && p->connected ? p->fused_dev : nullptr; }
+const TlPeerDev* tl_peer_fused_gather(TlPeer* p) { return p && p->connected ? p->fused_dev + 1 : nullptr; }
 
 int tl_peer_all_reduce(TlPeer* p, const float* in, float* out, hipStream_t s) {
   TL_REQUIRE(p && p->connected && in && out && in != out, "tl_peer_all_reduce: not connected / bad buffers");

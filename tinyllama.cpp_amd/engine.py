@@ -274,6 +274,18 @@ class Model:
         check(lib().tl_model_tp_peer_enabled(self.h, C.byref(out)), "tl_model_tp_peer_enabled")
         return bool(out.value)
 
+    def graph_nodes(self):
+        """Launches in the captured decode step (0: not captured), tl_model_graph_nodes."""
+        out = C.c_int(0)
+        check(lib().tl_model_graph_nodes(self.h, C.byref(out)), "tl_model_graph_nodes")
+        return int(out.value)
+
+    def tp_peer_fused(self):
+        """True when the exchanges ride inside the attn_output / ffn_down / lm_head launches (tl_model_tp_peer_fused)."""
+        out = C.c_int(0)
+        check(lib().tl_model_tp_peer_fused(self.h, C.byref(out)), "tl_model_tp_peer_fused")
+        return bool(out.value)
+
     def finalize(self):
         check(lib().tl_model_finalize(self.h), "tl_model_finalize")
 

@@ -116,6 +116,8 @@ def main():
     keep = {}  # host copies kept for the CPU-baseline sample: first layers + globals
     want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
 
+    preflight = {}  # TL_TP_PEER_FUSED value -> us per step of the pre-flight model (max over ranks), or "failed"
+
     def build(tp_rank, tp_size):
         model = engine.Model(cfg, tp_rank=tp_rank, tp_size=tp_size)
         if tp_size > 1:  # rank 0 makes the communicator id, torch.distributed carries it to the other ranks
@@ -146,24 +148,37 @@ def main():
                 # every rank then stays on RCCL.
                 import subprocess
                 import tempfile
-                # The children run the step in the form the bench would use: exchanges folded into the GEMV launches
-                # first, then (should that fail over real links) as launches of their own; TL_TP_PEER_FUSED pins one.
+                # The children run the step in both forms of the exchange (folded into the GEMV launches / launches of
+                # their own; TL_TP_PEER_FUSED pins one) and time 48 steps of their one-layer model, which is mostly its
+                # three exchanges: the ranks agree on the faster form that every child survived, as measured over the
+                # links of THIS node (single-lane pushes from a GEMV epilogue and coalesced pushes from an exchange
+                # kernel need not cost the same over xGMI; a one-GPU box cannot tell).
                 pinned = os.environ.get("TL_TP_PEER_FUSED")
-                linked = False
+                linked, best = False, (None, float("inf"))
                 for mode in ([pinned] if pinned is not None else ["1", "0"]):
                     box = [tempfile.mkdtemp(prefix="tl_peer_") if rank == 0 else None]
                     dist.broadcast_object_list(box, src=0)
                     cmd = [sys.executable, "-u", os.path.join(ROOT, "tools", "peer_latency.py"), "--worker", str(tp_rank),
                            str(tp_size), "--iters", "50", "--dir", box[0], "--device", str(local), "--rv-timeout", "30"]
+                    step_us = float("inf")
                     try:
                         pre_ok = subprocess.run(cmd, timeout=120, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                                                 env=dict(os.environ, TL_TP_PEER_FUSED=mode)).returncode == 0
+                        if pre_ok:
+                            step_us = float(json.load(open(os.path.join(box[0], f"lat_{tp_rank}.json")))["step_us"])
                     except Exception:
                         pre_ok = False
                     if agree(pre_ok):
-                        os.environ["TL_TP_PEER_FUSED"] = mode  # (read by tl_model_tp_peer_enable)
-                        linked = pkg_tp.peer_link(model, gather, agree)
-                        break
+                        t = torch.tensor([step_us], device="cuda", dtype=torch.float64)
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)  # (the same number on every rank: the same choice)
+                        preflight[mode] = round(float(t.item()), 1)
+                        if float(t.item()) < best[1]:
+                            best = (mode, float(t.item()))
+                    else:
+                        preflight[mode] = "failed"
+                if best[0] is not None:
+                    os.environ["TL_TP_PEER_FUSED"] = best[0]  # (read by tl_model_tp_peer_enable)
+                    linked = pkg_tp.peer_link(model, gather, agree)
                 if SHARE_GPU and not linked:
                     raise RuntimeError("ranks sharing one GPU can only be linked by the peer exchange, which was refused: "
                                        + engine.lib().tl_last_error().decode(errors="replace"))
@@ -304,6 +319,7 @@ def main():
         out["exchange_us_per_step"] = None if tp_fallback or ar.get("us") is None else round(2 * cfg["n_layers"] * ar["us"], 1)
         out["graph_captured"] = bool(model.graph_captured())
         fz = (not tp_fallback) and model.tp_peer_enabled() and model.tp_peer_fused()
+        out["preflight_step_us_by_fused"] = preflight
         out["launches_per_step"] = model.graph_nodes()  # (folded exchanges: the unsharded step's count)
         out["exchange_launches_per_step"] = 0 if tp_fallback or fz else 2 * cfg["n_layers"] + 1
         out["weight_bytes_per_token_per_rank"] = int(w_bytes)

@@ -40,8 +40,14 @@ def worker(rank, tp_size, hidden, iters, workdir, device=0, rv_timeout=120.0):
     us, nbytes = m.bench_kernel("tp_all_reduce", iters=iters, warmup=200)
     ids = m.generate_greedy(1, 0, 32)
     rv.agree(True)
+    import time
+    t0 = time.perf_counter()  # a step of this one-layer model is mostly its three exchanges: bench.py's pre-flight compares
+    m.generate_greedy(1, 0, 48)  # the two forms of the exchange (folded into the GEMVs / launches of their own) by this time
+    step_us = (time.perf_counter() - t0) / 48 * 1e6
+    rv.agree(True)
     with open(os.path.join(workdir, f"lat_{rank}.json"), "w") as f:
-        json.dump({"rank": rank, "us": us, "bytes": nbytes, "ids": [int(i) for i in ids]}, f)
+        json.dump({"rank": rank, "us": us, "bytes": nbytes, "ids": [int(i) for i in ids], "step_us": step_us,
+                   "fused": bool(m.tp_peer_fused())}, f)
     rv.agree(True)
     m.free()
     return 0
@@ -78,6 +84,8 @@ def main():
             same = all(r["ids"] == res[0]["ids"] for r in res)
             print(json.dumps({"tp": tp_size, "ranks_share_one_gpu": True, "hidden": a.hidden, "bytes": res[0]["bytes"],
                               "iters": a.iters, "us_per_all_reduce": [round(r["us"], 2) for r in res],
+                              "exchanges_folded_into_gemvs": res[0]["fused"],
+                              "us_per_step_of_the_one_layer_model": [round(r["step_us"], 1) for r in res],
                               "ranks_agree_on_tokens": same}))
     return rc
 

@@ -41,8 +41,12 @@ def worker(rank, tp_size, hidden, iters, workdir, device=0, rv_timeout=120.0):
     ids = m.generate_greedy(1, 0, 32)
     rv.agree(True)
     import time
-    t0 = time.perf_counter()  # a step of this one-layer model is mostly its three exchanges: bench.py's pre-flight compares
-    m.generate_greedy(1, 0, 48)  # the two forms of the exchange (folded into the GEMVs / launches of their own) by this time
+    # A step of this one-layer model is mostly its three exchanges: bench.py's pre-flight compares the two forms of the
+    # exchange (folded into the GEMVs / launches of their own) by this time. The short run in front is the barrier: its
+    # last exchange leaves the ranks within microseconds of each other (the file rendezvous above does not).
+    m.generate_greedy(1, 0, 8)
+    t0 = time.perf_counter()
+    m.generate_greedy(1, 0, 48)
     step_us = (time.perf_counter() - t0) / 48 * 1e6
     rv.agree(True)
     with open(os.path.join(workdir, f"lat_{rank}.json"), "w") as f:

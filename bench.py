@@ -86,6 +86,17 @@ def dist_setup(n_gpus):
 
 def main():
     args = parse()
+    # Watchdog (seconds; TL_BENCH_WATCHDOG, 900 by default for multi-rank runs): dump every thread's Python stack to stderr
+    # and exit instead of sitting in a collective for ever. Multi-rank runs also shorten the peer exchange's poll deadline
+    # (5 s by default in the library): the ranks enter every collective call together here (barriers in front of finalize),
+    # and a rank that is really gone should cost a second per exchange, not five, before the error return.
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    wd = int(os.environ.get("TL_BENCH_WATCHDOG", "900" if multi else "0"))
+    if wd > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(wd, exit=True)
+    if multi:
+        os.environ.setdefault("TL_TP_PEER_TIMEOUT_MS", "1000")
     rank, world, local, dist = dist_setup(args.gpus)
     from _pkg import load_package
     pkg = load_package()

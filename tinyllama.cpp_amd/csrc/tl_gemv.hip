@@ -48,6 +48,7 @@ struct GemvVec {
   // between kernel entry and a wave's first weight load
   int nthr, grid;
   const TlPeerDev* peer;  // PEER instantiations only: the exchange this launch carries (tl_internal.h)
+  int peer_gpw;           // ... and the row groups a wave has at most: its slice of the LDS stash holds 2 floats for each
 };
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
@@ -257,13 +258,17 @@ __device__ __forceinline__ void peer_push(const TlPeerDev* pd, unsigned e, int r
   for (int p = 0; p < TL_PEER_MAX_RANKS; ++p)
     if (p < tp && (ALL || p != rank)) peer_store(pd->rx[p] + at, w);
 }
-// The wave's own rows again (row groups first, first + stride, ... of a single-matrix launch: rows 2 rg and 2 rg + 1), one
-// row per lane, 32 row groups per pass: wait for every rank's word of the row (bounded by the deadline), then
+// End of a wave's work: its finished rows wait in the wave's LDS stash (2 floats per row group, in the order the wave
+// worked through first, first + stride, ...: rows 2 rg and 2 rg + 1 of a single-matrix launch). Pushing them from the
+// epilogue of every row group instead measured much slower where a wave has many row groups (lm_head): the pushes are
+// uncached stores, stores retire through the same in-order counter as the loads, and the step loop's counted waits then
+// sit behind a store's slow acknowledgement once per row group. Here: one row per lane, 32 row groups per pass: push the
+// row's word to every rank, wait for every rank's word of the row (bounded by the deadline), then
 // REDUCE: out[row] = sum in rank order 0 .. tp-1 (every rank computes the same bits); else: out[(q - rank) n + row] = rank
-// q's value for q != rank (out points at this rank's rows of the gathered vector).
+// q's value for q != rank (out points at this rank's rows of the gathered vector, which the epilogue stored directly).
 template <bool REDUCE>
 __device__ __forceinline__ void peer_collect(const TlPeerDev* pd, unsigned e, float* out, int rows, int first, int stride,
-                                             int total, int lane) {
+                                             int ngroups, const float* stash, int lane) {
   const int tp = pd->tp, rank = pd->rank, n = pd->n;
   const pu64* mine = pd->rx[0];
 #pragma unroll
@@ -271,10 +276,11 @@ __device__ __forceinline__ void peer_collect(const TlPeerDev* pd, unsigned e, fl
   mine += (size_t)(e & 1u) * (size_t)tp * (size_t)n;
   const pu64 deadline = __builtin_amdgcn_s_memrealtime() + pd->timeout_ticks;
   bool ok = true;
-  for (int base = first; base < total; base += 32 * stride) {
-    const int rg = base + (lane >> 1) * stride;
-    const int row = 2 * rg + (lane & 1);
-    if (rg < total && row < rows) {
+  for (int j0 = 0; j0 < ngroups; j0 += 32) {
+    const int j = j0 + (lane >> 1);
+    const int row = 2 * (first + j * stride) + (lane & 1);
+    if (j < ngroups && row < rows) {
+      peer_push<REDUCE>(pd, e, row, stash[2 * j + (lane & 1)]);
       const pu64* at = mine + row;
       pu64 w[TL_PEER_MAX_RANKS];
 #pragma unroll
@@ -324,10 +330,14 @@ struct StepMeta {
 // loads complete in order, so a load in the epilogue would drain the whole prefetch queue once per row group.
 template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP, bool PEER = false>
 __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const XRegs& xr, float* smem, int first,
-                                          int stride, int total, int lane, unsigned long long* ts, unsigned pe = 0) {
+                                          int stride, int total, int lane, unsigned long long* ts, unsigned pe = 0,
+                                          int peer_wave = 0) {
   const float* xs = smem + XS_SCRATCH;
   const int nchunks = a.cols >> 5;
   const int nspans = (nchunks + 63) >> 6;
+  // PEER: this wave's slice of the stash behind the x image, and the row groups it has finished
+  float* stash = smem + XS_SCRATCH + nchunks * XS_STRIDE + 2 * peer_wave * a.peer_gpw;
+  int ndone = 0;
   if (first >= total) {  // a wave without work only helps staging x
     if (STAMP) ts[3] = __builtin_readcyclecounter();
     stage_x_finish<XATTN>(a, xr, smem);
@@ -383,9 +393,9 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
         if (PAIR) {
           const float sg = 1.0f / (1.0f + expf(-y0));  // silu_cpu (utils.cpp:700-707), then * up (model.cpp:735)
           stg_f32(m.out + m.ra, (y0 * sg) * y1);
-        } else if (PEER) {  // the rows leave for the other ranks the moment they exist; collected below
-          peer_push<RESID>(a.peer, pe, m.ra, RESID ? st.r0 + y0 : y0);
-          if (m.ra + 1 < m.rows) peer_push<RESID>(a.peer, pe, m.ra + 1, RESID ? st.r1 + y1 : y1);
+        } else if (PEER) {  // into the wave's stash; pushed and collected at the end of the wave's work (peer_collect)
+          stash[2 * ndone] = RESID ? st.r0 + y0 : y0;
+          stash[2 * ndone + 1] = RESID ? st.r1 + y1 : y1;
           if (!RESID) {
             stg_f32(m.out + m.ra, y0);
             if (m.ra + 1 < m.rows) stg_f32(m.out + m.ra + 1, y1);
@@ -397,6 +407,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
       }
       acc0 = 0.f;
       acc1 = 0.f;
+      if (PEER) ++ndone;
     }
   };
 
@@ -422,7 +433,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   if (STAMP) ts[6] = __builtin_readcyclecounter();  // every load of this wave has been issued
   consume(cur, mc);
   if (STAMP && ts[5] == 0) ts[5] = __builtin_readcyclecounter();
-  if (PEER) peer_collect<RESID>(a.peer, pe, g.o0, g.w0.rows, first, stride, total, lane);
+  if (PEER) peer_collect<RESID>(a.peer, pe, g.o0, g.w0.rows, first, stride, ndone, stash, lane);
 }
 
 
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
       run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane);
     else
       run_class<TA, PAIR, RESID, XATTN, STAMP, PEER>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane,
-                                                     ts, pe);
+                                                     ts, pe, wave);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
@@ -841,7 +852,7 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
-  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged, 0, 0, a.peer};
+  L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged, 0, 0, a.peer, 0};
   if (a.peer)
     TL_REQUIRE(a.nseg == 1 && !a.pair && (a.resid || a.role == GEMV_LM_HEAD),
                "gemv: a launch that carries its exchange is one matrix with a residual (all-reduce) or the lm_head (all-gather)");
@@ -909,6 +920,12 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   const int total = classB ? totalA + L.t[nsegA] : totalA;
   const int waves = gemv_geometry(L, total);
   L.wavesA = waves;
+  if (a.peer) {  // the waves' stashes of finished rows behind the x image
+    L.v.peer_gpw = (total + L.grid * waves - 1) / (L.grid * waves);
+    L.lds += sizeof(float) * 2 * (size_t)L.v.peer_gpw * (size_t)waves;
+    TL_REQUIRE(L.lds <= 160 * 1024, "gemv: %d row groups per wave do not fit the LDS stash of a launch that carries its exchange",
+               L.v.peer_gpw);
+  }
   if (classB) {
     int wa = (int)(waves * bytesA / (bytesA + bytesB) + 0.5);
     if (wa < 1) wa = 1;
@@ -954,7 +971,7 @@ extern "C" int tl_debug_gemv_stamps(const tl_qweight* w, const float* x_dev, flo
   Launch L = {};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(w->cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "tl_debug_gemv_stamps: cols %d too large", w->cols);
-  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0, 0, 0, 0, nullptr};
+  L.v = GemvVec{x_dev, nullptr, nullptr, 0.f, w->cols, stamps_dev, nullptr, nullptr, 0, 0, 0, 0, nullptr, 0};
   for (int i = 0; i < 3; ++i) L.seg[i] = GemvSeg{qw_view(w), y_dev};
   L.t[0] = (w->rows + 1) / 2;
   L.nsegA = 1;

@@ -24,8 +24,11 @@ def worker(rank, tp_size, hidden, iters, workdir, device=0, rv_timeout=120.0):
     from tinyllama_cpp_amd import tp
     E.init(device)
     heads = hidden // 128
-    cfg = dict(S.SHAPES["llama-3-8b"], hidden=hidden, n_heads=heads, n_kv_heads=8, inter=512 * tp_size, n_layers=1,
-               vocab=1024 * tp_size, max_pos=64)
+    if hidden == 4096:  # ONE real layer of Llama-3-8B and its lm_head: the exchanges carry what the bench's will carry
+        cfg = dict(S.SHAPES["llama-3-8b"], n_layers=1, max_pos=64)
+    else:
+        cfg = dict(S.SHAPES["llama-3-8b"], hidden=hidden, n_heads=heads, n_kv_heads=8, inter=512 * tp_size, n_layers=1,
+                   vocab=1024 * tp_size, max_pos=64)
     cfg, tensors = S.build_model(cfg, "q4_k_m", seed=1)
     m = E.Model(cfg, tp_rank=rank, tp_size=tp_size)
     rv = tp.FileRendezvous(workdir, rank, tp_size, timeout=rv_timeout)

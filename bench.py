@@ -59,6 +59,10 @@ def parse():
 # device; the shards are linked by the peer exchange only). A REHEARSAL of the control flow, not a measurement: the line
 # carries "rehearsal" and its numbers mean nothing.
 SHARE_GPU = os.environ.get("TL_BENCH_SHARE_GPU", "0") == "1"
+# where the tensors of the host-side collectives (handles, flags, times) live: on the GPU for RCCL; in host memory for the
+# rehearsal's gloo group (gloo collectives on CUDA tensors stalled in all_gather once in about ten rehearsal runs, both
+# ranks inside the call: profiles/r02_x_rehearsal_stall_traceback.txt)
+HOST_DEV = "cpu" if SHARE_GPU else "cuda"
 if SHARE_GPU and int(os.environ.get("WORLD_SIZE", "1")) > 1:
     # exchanges folded into GEMV launches wait for the same launch of the other ranks: on ONE device all ranks' launches
     # have to fit on the chip together (csrc/tl_gemv.hip TL_GEMV_CUS); with a device per rank nothing is capped
@@ -133,7 +137,7 @@ def main():
         model = engine.Model(cfg, tp_rank=tp_rank, tp_size=tp_size)
         if tp_size > 1:  # rank 0 makes the communicator id, torch.distributed carries it to the other ranks
             import torch
-            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            uid = torch.zeros(128, dtype=torch.uint8, device=HOST_DEV)
             if rank == 0:
                 uid.copy_(torch.frombuffer(bytearray(engine.tp_unique_id()), dtype=torch.uint8))
             dist.broadcast(uid, src=0)
@@ -143,13 +147,13 @@ def main():
             # when every rank passes their self-check, else the RCCL calls (TL_TP_PEER=0 forces those)
             if os.environ.get("TL_TP_PEER", "1") != "0":
                 def gather(b):
-                    mine = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+                    mine = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(HOST_DEV)
                     parts = [torch.empty_like(mine) for _ in range(tp_size)]
                     dist.all_gather(parts, mine)
                     return [p_.cpu().numpy().tobytes() for p_ in parts]
 
                 def agree(flag):
-                    t = torch.tensor([1 if flag else 0], device="cuda")
+                    t = torch.tensor([1 if flag else 0], device=HOST_DEV)
                     dist.all_reduce(t, op=dist.ReduceOp.MIN)
                     return bool(int(t.item()))
 
@@ -180,7 +184,7 @@ def main():
                     except Exception:
                         pre_ok = False
                     if agree(pre_ok):
-                        t = torch.tensor([step_us], device="cuda", dtype=torch.float64)
+                        t = torch.tensor([step_us], device=HOST_DEV, dtype=torch.float64)
                         dist.all_reduce(t, op=dist.ReduceOp.MAX)  # (the same number on every rank: the same choice)
                         preflight[mode] = round(float(t.item()), 1)
                         if float(t.item()) < best[1]:
@@ -220,7 +224,7 @@ def main():
             model = build(rank, world)
         except Exception as e:
             err = str(e)[:200]
-        ok = torch.tensor([0 if err else 1], device="cuda")
+        ok = torch.tensor([0 if err else 1], device=HOST_DEV)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
             errs = [None] * world
@@ -257,7 +261,7 @@ def main():
     dt = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([dt], device="cuda")
+        t = torch.tensor([dt], device=HOST_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert len(ids) == args.steps and all(0 <= int(i) < cfg["vocab"] for i in ids)

@@ -141,6 +141,8 @@ def test_import_rejects_garbage_handles(pkg):
     assert len(handle) == 64
     with pytest.raises(TlError):
         m.tp_peer_import([handle, bytes(range(64))])  # rank 1's handle is not a handle
+    with pytest.raises(TlError):
+        m.tp_peer_enable(True)  # exported but never linked: enabling would skip exchanges that cannot run
     assert not m.tp_peer_enabled()
     with pytest.raises(TlError):
         E.Model(dict(pkg.synth.SHAPES["tiny"]), tp_rank=0, tp_size=1).tp_peer_export()  # tp_size 1 has nothing to link

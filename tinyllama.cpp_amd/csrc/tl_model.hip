@@ -1837,7 +1837,7 @@ extern "C" int tl_model_tp_peer_import(tl_model* m, const void* handles, int* ok
 }
 extern "C" int tl_model_tp_peer_enable(tl_model* m, int on) {
   TL_REQUIRE(m && !m->finalized, "tl_model_tp_peer_enable: call before tl_model_finalize");
-  TL_REQUIRE(!on || m->peer, "tl_model_tp_peer_enable: nothing imported");
+  TL_REQUIRE(!on || (m->peer && tl_peer_fused_reduce(m->peer)), "tl_model_tp_peer_enable: nothing imported (tl_model_tp_peer_import first)");
   m->peer_on = on != 0;
   if (const char* e = getenv("TL_TP_PEER_FUSED")) m->peer_fused = atoi(e) != 0;
   return 0;

@@ -133,8 +133,11 @@ def main():
 
     preflight = {}  # TL_TP_PEER_FUSED value -> us per step of the pre-flight model (max over ranks), or "failed"
 
+    made = []  # every model build() created, so that a build that raised half-way can still be freed
+
     def build(tp_rank, tp_size):
         model = engine.Model(cfg, tp_rank=tp_rank, tp_size=tp_size)
+        made.append(model)
         if tp_size > 1:  # rank 0 makes the communicator id, torch.distributed carries it to the other ranks
             import torch
             uid = torch.zeros(128, dtype=torch.uint8, device=HOST_DEV)
@@ -216,22 +219,34 @@ def main():
         model = build(0, 1)
     else:
         # tensor parallel over the ranks. If the group cannot be set up (an exception on any rank, agreed on through
-        # torch.distributed), every rank falls back to a whole-model replica and the line says so: weak scaling, no
-        # exchange, labelled as a fallback. (A hang inside a collective cannot be caught this way.)
+        # torch.distributed) the ranks try once more on the library collectives alone (TL_TP_PEER=0: a peer exchange that
+        # passed its pre-flight and then failed in the full model's warm-up step leaves its group out of step, a fresh
+        # group on RCCL is not affected); if that fails too, every rank falls back to a whole-model replica and the line
+        # says so: weak scaling, no exchange, labelled as a fallback. (A hang inside a collective cannot be caught this way.)
         import torch
-        model, err = None, ""
-        try:
-            model = build(rank, world)
-        except Exception as e:
-            err = str(e)[:200]
-        ok = torch.tensor([0 if err else 1], device=HOST_DEV)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 0:
+        model, tp_errors = None, []
+        attempts = ["as configured"] + (["rccl only"] if not SHARE_GPU and os.environ.get("TL_TP_PEER", "1") != "0" else [])
+        for attempt in attempts:
+            if attempt == "rccl only":
+                os.environ["TL_TP_PEER"] = "0"
+            err = ""
+            try:
+                model = build(rank, world)
+            except Exception as e:
+                err = str(e)[:200]
+            ok = torch.tensor([0 if err else 1], device=HOST_DEV)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                break
             errs = [None] * world
             dist.all_gather_object(errs, err)
-            tp_fallback = next((e for e in errs if e), "unknown")
-            if model is not None:
-                model.free()
+            tp_errors.append(f"{attempt}: " + next((e for e in errs if e), "unknown"))
+            for m_ in made:  # (also the one a build that raised never returned)
+                m_.free()
+            made.clear()
+            model = None
+        if model is None:
+            tp_fallback = "; ".join(tp_errors)
             model = build(0, 1)
     t_load = time.time() - t_load
 
@@ -335,6 +350,8 @@ def main():
         out["graph_captured"] = bool(model.graph_captured())
         fz = (not tp_fallback) and model.tp_peer_enabled() and model.tp_peer_fused()
         out["preflight_step_us_by_fused"] = preflight
+        if not tp_fallback and tp_errors:
+            out["tp_retries"] = tp_errors  # (the group that ran is the second attempt, on RCCL alone)
         out["launches_per_step"] = model.graph_nodes()  # (folded exchanges: the unsharded step's count)
         out["exchange_launches_per_step"] = 0 if tp_fallback or fz else 2 * cfg["n_layers"] + 1
         out["weight_bytes_per_token_per_rank"] = int(w_bytes)

@@ -113,6 +113,17 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   for (int g = 0; g < G; ++g)
 #pragma unroll
     for (int v = 0; v < NV; ++v) qf[g][v] = *reinterpret_cast<const f32x4*>(a.q + (size_t)(head0 + g) * HD + 64 * v + 4 * ln);
+  // FUSE: k and v of the new position, asked for here with everything else (every workgroup loads them, the owner's last
+  // wave uses them: loading them where they are used put one more round trip behind that wave's fold, on the path of
+  // the workgroup every launch waits for)
+  f32x4 kn[NV], vn[NV];
+  if (FUSE) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      kn[v] = *reinterpret_cast<const f32x4*>(a.k + (size_t)kvh * HD + 64 * v + 4 * ln);
+      vn[v] = *reinterpret_cast<const f32x4*>(a.v + (size_t)kvh * HD + 64 * v + 4 * ln);
+    }
+  }
 
   const float* kbase = a.kc + (size_t)t0 * kv_dim + hoff + 4 * ln;
   const float* vbase = a.vc + (size_t)t0 * kv_dim + hoff + 4 * ln;
@@ -216,6 +227,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
         r[2] = o0; r[3] = o1;
         qf[g][v] = r;
       }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {  // ... and of the new position's key
+      f32x4 r;
+      float o0, o1;
+      rope2(kn[v][0], kn[v][1], tq[v][0], tq[v][1], o0, o1);
+      r[0] = o0; r[1] = o1;
+      rope2(kn[v][2], kn[v][3], tq[v][2], tq[v][3], o0, o1);
+      r[2] = o0; r[3] = o1;
+      kn[v] = r;
+    }
   }
   if (uc0 == 2) fold_batch(std::integral_constant<int, 2>{});
   else if (uc0 == 4) fold_batch(std::integral_constant<int, 4>{});
@@ -227,20 +248,10 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
     fold_batch(std::integral_constant<int, U>{});
   }
   if (owner && wave == ATT_NW - 1) {
-    // the new position (the last wave has the fewest cache rows): rotate k, take v, write both into the cache (one of the
-    // workgroups that share the kv head does) and fold them from registers
-    f32x4 kn[NV], vn[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) tq[v] = *reinterpret_cast<const f32x4*>(a.table + (size_t)pos * HD + 64 * v + 4 * ln);
+    // the new position (the last wave has the fewest cache rows): its rotated k and its v (loaded and rotated at the top)
+    // go into the cache (one of the workgroups that share the kv head writes) and are folded from registers
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      const f32x4 kr = *reinterpret_cast<const f32x4*>(a.k + (size_t)kvh * HD + 64 * v + 4 * ln);
-      vn[v] = *reinterpret_cast<const f32x4*>(a.v + (size_t)kvh * HD + 64 * v + 4 * ln);
-      float o0, o1;
-      rope2(kr[0], kr[1], tq[v][0], tq[v][1], o0, o1);
-      kn[v][0] = o0; kn[v][1] = o1;
-      rope2(kr[2], kr[3], tq[v][2], tq[v][3], o0, o1);
-      kn[v][2] = o0; kn[v][3] = o1;
       if (sub == 0 && blockIdx.z == 0) {
         *reinterpret_cast<f32x4*>(a.kc + (size_t)pos * kv_dim + hoff + 64 * v + 4 * ln) = kn[v];
         *reinterpret_cast<f32x4*>(a.vc + (size_t)pos * kv_dim + hoff + 64 * v + 4 * ln) = vn[v];

@@ -60,6 +60,24 @@ __device__ __forceinline__ float row_sum16(float v) {
   v = dpp_add<0x140, 0xf>(v);  // row_mirror
   return v;
 }
+// max / sum over 32 consecutive lanes (two DPP rows), result in every one of them: four DPP steps inside the rows and ONE
+// LDS-path exchange between them (the xor butterfly is five dependent ds_bpermute round trips per reduction)
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, t));
+}
+__device__ __forceinline__ float max32(float v) {
+  v = dpp_max<0xB1>(v);
+  v = dpp_max<0x4E>(v);
+  v = dpp_max<0x141>(v);
+  v = dpp_max<0x140>(v);
+  return fmaxf(v, __shfl_xor(v, 16));
+}
+__device__ __forceinline__ float sum32(float v) {
+  v = row_sum16(v);
+  return v + __shfl_xor(v, 16);
+}
 // agent-scope accesses for data handed between workgroups inside one launch (the L2s of the 8 XCDs are not coherent with
 // each other for ordinary accesses)
 __device__ __forceinline__ void st_agent(float* p, float v) {
@@ -279,14 +297,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
     const int g = tid / NR, r = tid % NR;
     const float* rec = part + (size_t)(r * G + g) * RECL;
     const float mr = rec[HD];
-    float M = mr;
-#pragma unroll
-    for (int o = NR / 2; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o));
+    static_assert(NR == 32, "the reductions below run over 32 consecutive lanes per head");
+    const float M = max32(mr);
     const float w = safe_exp_diff(mr, M);
     wts[r * G + g] = w;
-    float L = rec[HD + 1] * w;
-#pragma unroll
-    for (int o = NR / 2; o >= 1; o >>= 1) L += __shfl_xor(L, o);
+    const float L = sum32(rec[HD + 1] * w);
     if (r == 0) {
       red[g] = M;
       red[8 + g] = L;
@@ -360,14 +375,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
     const float* rec = a.ws + ((size_t)(head0 + gg) * TL_ATTN_MAX_SPLITS + (sp < active ? sp : active - 1)) * RECL;
     const float ms = sp < active ? ld_agent(rec + HD) : -INFINITY;
     const float ls = ld_agent(rec + HD + 1);
-    float M = ms;
-#pragma unroll
-    for (int x = TL_ATTN_MAX_SPLITS / 2; x >= 1; x >>= 1) M = fmaxf(M, __shfl_xor(M, x));
+    static_assert(TL_ATTN_MAX_SPLITS == 32, "the reductions below run over 32 consecutive lanes per head");
+    const float M = max32(ms);
     const float w = sp < active ? expf(ms - M) : 0.f;
     wts[tid] = w;
-    float L = ls * w;
-#pragma unroll
-    for (int x = TL_ATTN_MAX_SPLITS / 2; x >= 1; x >>= 1) L += __shfl_xor(L, x);
+    const float L = sum32(ls * w);
     if (sp == 0) {
       red[gg] = M;
       red[8 + gg] = L;

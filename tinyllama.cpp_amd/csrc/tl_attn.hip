@@ -99,8 +99,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   constexpr int RECL = HD + 4;           // partial record: out[HD], max, sum, 2 pad (16-B aligned)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* red = sm;                       // 64 floats: M[g] at g, L at 8 + g
-  float* wts = red + 64;                 // [NR][G] weight of a row group's record in the split's partial
-  float* part = wts + NR * G;            // [NR][G][RECL]
+  float* wts = red + 64;                 // [G][NR] running max of every row group's record (the merge phase: split weights)
+  float* lls = wts + NR * G;             // [G][NR] running sum of every row group's record
+  float* part = lls + NR * G;            // [NR][G][RECL]
   const int kvh = blockIdx.x, split = blockIdx.y;
   const int head0 = (kvh * a.zparts + blockIdx.z) * G;  // a.zparts workgroups share a kv head, G query heads each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -288,41 +289,38 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
 #pragma unroll
     for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(rec + 64 * v + 4 * ln) = acc[g][v];
     if (ln == 0) {
-      rec[HD] = m[g];
-      rec[HD + 1] = l[g];
+      wts[g * NR + rg] = m[g];
+      lls[g * NR + rg] = l[g];
     }
   }
   __syncthreads();
-  if (tid < NR * G) {  // NR = 32 consecutive lanes per head: split-wide max, weights and sum
-    const int g = tid / NR, r = tid % NR;
-    const float* rec = part + (size_t)(r * G + g) * RECL;
-    const float mr = rec[HD];
-    static_assert(NR == 32, "the reductions below run over 32 consecutive lanes per head");
-    const float M = max32(mr);
-    const float w = safe_exp_diff(mr, M);
-    wts[r * G + g] = w;
-    const float L = sum32(rec[HD + 1] * w);
-    if (r == 0) {
-      red[g] = M;
-      red[8 + g] = L;
-    }
-  }
-  __syncthreads();
+  static_assert(NR == 32, "a head's 32 row-group states are read as eight float4");
   const bool merge = a.done_cnt != nullptr && active >= TL_ATTN_MERGE_MIN;
   // ws[head][split] = {out[HD] (unnormalised), max, sum}: four lanes share an output quad, each sums a quarter of the
-  // row groups (in a fixed order), then the quad is summed with two DPP steps
+  // row groups (in a fixed order), then the quad is summed with two DPP steps. Every thread takes the split-wide max of its
+  // head from the 32 row-group maxima itself (eight broadcast LDS reads) and the weights exp(m_r - M) of its own eight row
+  // groups: a phase of its own for them (32 lanes per head, two reductions, one more barrier) was 0.3 us of every launch.
   for (int i = tid; i < G * HD; i += ATT_THREADS) {
     const int rq = i & 3, d4 = (i >> 2) % (HD / 4), g = i / HD;
+    float M = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < NR / 4; ++q) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(wts + g * NR + 4 * q);
+      M = fmaxf(fmaxf(M, fmaxf(t[0], t[1])), fmaxf(t[2], t[3]));
+    }
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+    float L = 0.f;
 #pragma unroll
     for (int j = 0; j < NR / 4; ++j) {
       const int r = rq * (NR / 4) + j;
       const f32x4 x = *reinterpret_cast<const f32x4*>(part + (size_t)(r * G + g) * RECL + 4 * d4);
-      const float w = wts[r * G + g];
+      const float w = safe_exp_diff(wts[g * NR + r], M);
+      L = fmaf(lls[g * NR + r], w, L);
       o[0] = fmaf(x[0], w, o[0]); o[1] = fmaf(x[1], w, o[1]); o[2] = fmaf(x[2], w, o[2]); o[3] = fmaf(x[3], w, o[3]);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = dpp_add<0x4E, 0xf>(dpp_add<0xB1, 0xf>(o[e]));
+    L = dpp_add<0x4E, 0xf>(dpp_add<0xB1, 0xf>(L));
     if (rq == 0) {
       float* rec = a.ws + ((size_t)(head0 + g) * TL_ATTN_MAX_SPLITS + split) * RECL;
       if (merge) {
@@ -330,14 +328,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
 #pragma unroll
         for (int e = 0; e < 4; ++e) st_agent(rec + 4 * d4 + e, o[e]);
         if (d4 == 0) {
-          st_agent(rec + HD, red[g]);
-          st_agent(rec + HD + 1, red[8 + g]);
+          st_agent(rec + HD, M);
+          st_agent(rec + HD + 1, L);
         }
       } else {
         *reinterpret_cast<f32x4*>(rec + 4 * d4) = o;
         if (d4 == 0) {
-          rec[HD] = red[g];
-          rec[HD + 1] = red[8 + g];
+          rec[HD] = M;
+          rec[HD + 1] = L;
         }
       }
     }
@@ -443,7 +441,7 @@ template <int HD, int G>
 int launch_hg(const AttnArgs& a_in, bool fuse, hipStream_t s) {
   AttnArgs a = a_in;
   a.zparts = (a.nh / a.nkv) / G;
-  const size_t lds = sizeof(float) * (64 + (size_t)ATT_NW * 4 * G + (size_t)ATT_NW * 4 * G * (HD + 4));
+  const size_t lds = sizeof(float) * (64 + 2 * (size_t)ATT_NW * 4 * G + (size_t)ATT_NW * 4 * G * (HD + 4));
   const dim3 grid(a.nkv, TL_ATTN_MAX_SPLITS, (a.nh / a.nkv) / G);
   if (fuse) {
     static TlDeviceOnce lds_raised;  // per kernel instantiation, per device

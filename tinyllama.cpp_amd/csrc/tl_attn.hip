@@ -101,7 +101,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   float* red = sm;                       // 64 floats: M[g] at g, L at 8 + g
   float* wts = red + 64;                 // [G][NR] running max of every row group's record (the merge phase: split weights)
   float* lls = wts + NR * G;             // [G][NR] running sum of every row group's record
-  float* part = lls + NR * G;            // [NR][G][RECL]
+  float* wl = lls + NR * G;              // [ATT_NW][NR] per wave: the weights of its head's row groups (output loop)
+  float* part = wl + ATT_NW * NR;        // [NR][G][RECL]
   const int kvh = blockIdx.x, split = blockIdx.y;
   const int head0 = (kvh * a.zparts + blockIdx.z) * G;  // a.zparts workgroups share a kv head, G query heads each
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -308,13 +309,22 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
       const f32x4 t = *reinterpret_cast<const f32x4*>(wts + g * NR + 4 * q);
       M = fmaxf(fmaxf(M, fmaxf(t[0], t[1])), fmaxf(t[2], t[3]));
     }
+    // a wave's 64 threads share one head (HD >= 64): lane l computes the weight of row group l % 32 once and leaves it in
+    // the wave's LDS strip; everybody reads back its own eight (LDS operations of a wave execute in order: no barrier).
+    // Eight exps per thread instead were ~240 instructions in every wave of the workgroup.
+    static_assert(HD % 64 == 0, "one head per wave in the output loop");
+    wl[wave * NR + (lane & 31)] = safe_exp_diff(wts[g * NR + (lane & 31)], M);
+    __builtin_amdgcn_wave_barrier();
+    f32x4 wv[2];
+    wv[0] = *reinterpret_cast<const f32x4*>(wl + wave * NR + rq * (NR / 4));
+    wv[1] = *reinterpret_cast<const f32x4*>(wl + wave * NR + rq * (NR / 4) + 4);
     f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
     float L = 0.f;
 #pragma unroll
     for (int j = 0; j < NR / 4; ++j) {
       const int r = rq * (NR / 4) + j;
       const f32x4 x = *reinterpret_cast<const f32x4*>(part + (size_t)(r * G + g) * RECL + 4 * d4);
-      const float w = safe_exp_diff(wts[g * NR + r], M);
+      const float w = wv[j >> 2][j & 3];
       L = fmaf(lls[g * NR + r], w, L);
       o[0] = fmaf(x[0], w, o[0]); o[1] = fmaf(x[1], w, o[1]); o[2] = fmaf(x[2], w, o[2]); o[3] = fmaf(x[3], w, o[3]);
     }
@@ -441,7 +451,7 @@ template <int HD, int G>
 int launch_hg(const AttnArgs& a_in, bool fuse, hipStream_t s) {
   AttnArgs a = a_in;
   a.zparts = (a.nh / a.nkv) / G;
-  const size_t lds = sizeof(float) * (64 + 2 * (size_t)ATT_NW * 4 * G + (size_t)ATT_NW * 4 * G * (HD + 4));
+  const size_t lds = sizeof(float) * (64 + 2 * (size_t)ATT_NW * 4 * G + (size_t)ATT_NW * ATT_NW * 4 + (size_t)ATT_NW * 4 * G * (HD + 4));
   const dim3 grid(a.nkv, TL_ATTN_MAX_SPLITS, (a.nh / a.nkv) / G);
   if (fuse) {
     static TlDeviceOnce lds_raised;  // per kernel instantiation, per device

@@ -187,6 +187,65 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   // folds `cnt` row slots (K rows kk_, V rows vv_, validity bits valid_) into the running state
   auto fold = [&](const f32x4* kk_, const f32x4* vv_, unsigned valid_, auto cnt_c) __attribute__((always_inline)) {
     constexpr int cnt = decltype(cnt_c)::value;
+    if constexpr (G == 4) {
+      // Four heads per workgroup: the 16 lanes of a row hold the SAME scores of all four heads after the row sums, and the
+      // exps (a correction and one weight per slot and head: 4 (1 + cnt) of ~15 instructions each, the largest single
+      // item of this kernel's arithmetic, which at long context is what bounds it) were computed identically in every
+      // lane. Here lane ln computes them for head ln % 4 only and the quad hands them round with DPP broadcasts: the same
+      // values, a quarter of the exps.
+      float s[G][cnt], mx[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        mx[g] = m[g];
+#pragma unroll
+        for (int u = 0; u < cnt; ++u) {
+          float d = dot4(qf[g][0], kk_[u * NV]);
+          if (NV == 2) d += dot4(qf[g][NV - 1], kk_[u * NV + NV - 1]);
+          d = row_sum16(d);
+          s[g][u] = (valid_ >> u & 1u) ? d * a.scale : -INFINITY;
+          mx[g] = fmaxf(mx[g], s[g][u]);
+        }
+      }
+      const int gq = lane & 3;
+      auto sel4 = [&](float x0, float x1, float x2, float x3) { return gq == 0 ? x0 : gq == 1 ? x1 : gq == 2 ? x2 : x3; };
+      const float mxs = sel4(mx[0], mx[1], mx[2], mx[3]);
+      const float cs = safe_exp_diff(sel4(m[0], m[1], m[2], m[3]), mxs);  // (0 while nothing is valid: the state stays empty)
+      float ps[cnt];
+#pragma unroll
+      for (int u = 0; u < cnt; ++u)
+        ps[u] = (valid_ >> u & 1u) ? expf(sel4(s[0][u], s[1][u], s[2][u], s[3][u]) - mxs) : 0.f;
+      auto apply = [&](auto g_c) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_c)::value;
+        constexpr int QP = g * 0x55;  // quad_perm: every lane of the quad reads lane g
+        auto bcast = [&](float x) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), QP, 0xf, 0xf, false));
+        };
+        const float corr = bcast(cs);
+        m[g] = mx[g];
+        l[g] *= corr;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          acc[g][v][0] *= corr; acc[g][v][1] *= corr; acc[g][v][2] *= corr; acc[g][v][3] *= corr;
+        }
+#pragma unroll
+        for (int u = 0; u < cnt; ++u) {
+          const float p = bcast(ps[u]);
+          l[g] += p;
+#pragma unroll
+          for (int v = 0; v < NV; ++v) {
+            acc[g][v][0] = fmaf(p, vv_[u * NV + v][0], acc[g][v][0]);
+            acc[g][v][1] = fmaf(p, vv_[u * NV + v][1], acc[g][v][1]);
+            acc[g][v][2] = fmaf(p, vv_[u * NV + v][2], acc[g][v][2]);
+            acc[g][v][3] = fmaf(p, vv_[u * NV + v][3], acc[g][v][3]);
+          }
+        }
+      };
+      apply(std::integral_constant<int, 0>{});
+      apply(std::integral_constant<int, 1>{});
+      apply(std::integral_constant<int, 2>{});
+      apply(std::integral_constant<int, 3>{});
+      return;
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float s[cnt];

@@ -155,6 +155,58 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
         vv[u][v] = *reinterpret_cast<const f32x4*>(vbase + off + 64 * v);
       }
     }
+    if constexpr (G == 4) {
+      // the exps of the four heads once per quad (lane l: head l % 4, DPP quad broadcasts) instead of identically in all 16
+      // lanes of a row: as in tl_attn.hip's fold (same values, a quarter of the exps)
+      float s[G][U], mx[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        mx[g] = m[g];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float d = 0.f;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+            d += (qf[g][v][0] * kk[u][v][0] + qf[g][v][1] * kk[u][v][1]) + (qf[g][v][2] * kk[u][v][2] + qf[g][v][3] * kk[u][v][3]);
+          d = batch_row_sum16(d);
+          s[g][u] = valid[u] ? d * a.scale : -INFINITY;
+          mx[g] = fmaxf(mx[g], s[g][u]);
+        }
+      }
+      const int gq = lane & 3;
+      auto sel4 = [&](float x0, float x1, float x2, float x3) { return gq == 0 ? x0 : gq == 1 ? x1 : gq == 2 ? x2 : x3; };
+      const float mxs = sel4(mx[0], mx[1], mx[2], mx[3]);
+      const float cs = exp_diff(sel4(m[0], m[1], m[2], m[3]), mxs);  // (0 while nothing is valid: the state stays empty)
+      float ps[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) ps[u] = valid[u] ? expf(sel4(s[0][u], s[1][u], s[2][u], s[3][u]) - mxs) : 0.f;
+      auto apply = [&](auto g_c) __attribute__((always_inline)) {
+        constexpr int g = decltype(g_c)::value;
+        constexpr int QP = g * 0x55;  // quad_perm: every lane of the quad reads lane g
+        auto bcast = [&](float x) {
+          return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), QP, 0xf, 0xf, false));
+        };
+        const float corr = bcast(cs);
+        m[g] = mx[g];
+        l[g] *= corr;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[g][v] *= corr;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float p = bcast(ps[u]);
+          l[g] += p;
+#pragma unroll
+          for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[g][v][e] = fmaf(p, vv[u][v][e], acc[g][v][e]);
+        }
+      };
+      apply(std::integral_constant<int, 0>{});
+      apply(std::integral_constant<int, 1>{});
+      apply(std::integral_constant<int, 2>{});
+      apply(std::integral_constant<int, 3>{});
+      continue;
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       float s[U];

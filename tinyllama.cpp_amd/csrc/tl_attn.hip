@@ -187,12 +187,12 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
   // folds `cnt` row slots (K rows kk_, V rows vv_, validity bits valid_) into the running state
   auto fold = [&](const f32x4* kk_, const f32x4* vv_, unsigned valid_, auto cnt_c) __attribute__((always_inline)) {
     constexpr int cnt = decltype(cnt_c)::value;
-    if constexpr (G == 4) {
-      // Four heads per workgroup: the 16 lanes of a row hold the SAME scores of all four heads after the row sums, and the
+    if constexpr (G >= 2) {
+      // Several heads per workgroup: the 16 lanes of a row hold the SAME scores of all of them after the row sums, and the
       // exps (a correction and one weight per slot and head: 4 (1 + cnt) of ~15 instructions each, the largest single
       // item of this kernel's arithmetic, which at long context is what bounds it) were computed identically in every
-      // lane. Here lane ln computes them for head ln % 4 only and the quad hands them round with DPP broadcasts: the same
-      // values, a quarter of the exps.
+      // lane. Here lane ln computes them for head ln % 4 only (with fewer than four heads the spare lanes repeat
+      // the last one) and the quad hands them round with DPP broadcasts: the same values, 1 / G of the exps.
       float s[G][cnt], mx[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -208,12 +208,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
       }
       const int gq = lane & 3;
       auto sel4 = [&](float x0, float x1, float x2, float x3) { return gq == 0 ? x0 : gq == 1 ? x1 : gq == 2 ? x2 : x3; };
-      const float mxs = sel4(mx[0], mx[1], mx[2], mx[3]);
-      const float cs = safe_exp_diff(sel4(m[0], m[1], m[2], m[3]), mxs);  // (0 while nothing is valid: the state stays empty)
+      constexpr int G1 = 1, G2 = G > 2 ? 2 : G - 1, G3 = G > 3 ? 3 : G - 1;  // (heads of lanes 1, 2, 3 of a quad)
+      const float mxs = sel4(mx[0], mx[G1], mx[G2], mx[G3]);
+      const float cs = safe_exp_diff(sel4(m[0], m[G1], m[G2], m[G3]), mxs);  // (0 while nothing is valid: the state stays empty)
       float ps[cnt];
 #pragma unroll
       for (int u = 0; u < cnt; ++u)
-        ps[u] = (valid_ >> u & 1u) ? expf(sel4(s[0][u], s[1][u], s[2][u], s[3][u]) - mxs) : 0.f;
+        ps[u] = (valid_ >> u & 1u) ? expf(sel4(s[0][u], s[G1][u], s[G2][u], s[G3][u]) - mxs) : 0.f;
       auto apply = [&](auto g_c) __attribute__((always_inline)) {
         constexpr int g = decltype(g_c)::value;
         constexpr int QP = g * 0x55;  // quad_perm: every lane of the quad reads lane g
@@ -242,8 +243,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_decode_split_kernel(AttnArgs
       };
       apply(std::integral_constant<int, 0>{});
       apply(std::integral_constant<int, 1>{});
-      apply(std::integral_constant<int, 2>{});
-      apply(std::integral_constant<int, 3>{});
+      if constexpr (G > 2) apply(std::integral_constant<int, 2>{});
+      if constexpr (G > 3) apply(std::integral_constant<int, 3>{});
       return;
     }
 #pragma unroll

@@ -301,7 +301,7 @@ def main():
     # above are the clean numbers): kept for the non-GEMV kernels
     prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_w_gate_up_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r02_zz_gate_up_traffic.json")
     if args.workload == "llama-3-8b" and world == 1 and os.path.exists(tpath):  # PMC pass of this kernel on this workload (profiles/)
         traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
 

@@ -103,6 +103,11 @@ SIGNATURES = {
     "tl_tp_local_group_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, C.POINTER(C.c_int)],
 }
 
+# include/tlhip_debug.h: measurement / diagnostic hooks (not part of the boundary)
+DEBUG_SIGNATURES = {
+    "tl_chain_set_stamps": [_vp, _sz],
+}
+
 _lib = None
 
 
@@ -116,7 +121,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.tl_last_error.restype = C.c_char_p
         L.tl_last_error.argtypes = []
-        for name, argtypes in SIGNATURES.items():
+        for name, argtypes in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
             fn = getattr(L, name)
             fn.restype = C.c_int
             fn.argtypes = argtypes

@@ -23,10 +23,12 @@
 //   - nibble/byte unpack is v_and/v_lshr + v_cvt_f32_ubyteN, FP32 FMA chains, DPP wave reduction;
 //   - epilogues: plain store, residual add, or SwiGLU of a gate/up row pair.
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
 #include "tl_internal.h"
+#include "tlhip_debug.h"
 
 #include "tl_chunk.h"
 
@@ -50,6 +52,78 @@ struct GemvVec {
   const TlPeerDev* peer;  // PEER instantiations only: the exchange this launch carries (tl_internal.h)
   int peer_gpw;           // ... and the row groups a wave has at most: its slice of the LDS stash holds 2 floats for each
 };
+
+// ---- chained launches (tl_launch_chain below): several GEMVs of the decode step inside ONE launch ---------------------
+// A chain launch is a 2-D grid (workgroups of a task, tasks): the workgroups of task j+1 are dispatched behind those of
+// task j and take a CU as soon as one has room, issue their first weight loads (constants) and only then wait for task j,
+// so that kernel boundary, argument fetch and the first HBM round trip of a launch overlap the tail of its predecessor.
+// Hand-off (MI355X_MICROARCH.md, "Valid forms", table row 1): every activation word that crosses a task edge is stored
+// with an agent-scope (sc1, write-through) store and loaded with sc1 loads; every storing wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, one lane adds 1 to the task's arrival counter (8 shards on
+// lines of their own: 256 arrivals on one word serialise at ~12 ns each); the consumer's wave 0 polls the shards with sc1
+// loads (bounded by a deadline: a hand-off that never comes becomes an error word, not a hung GPU) and releases the other
+// waves through a workgroup barrier. Counters only grow: the target is (generation + 1) x arrivals per step, with the
+// generation word advanced once per step by a kernel of its own (no reset, no dependence on stale zeros).
+// Deadlock freedom rests on in-order dispatch inside one grid (x fastest, then y): a waiting workgroup can only hold a CU
+// if every workgroup of the task it waits for was placed before it.
+constexpr int CHAIN_SHARDS = 8;
+constexpr int CHAIN_SHARD_WORDS = 32;                                // 128 B apart
+constexpr int CHAIN_TASK_WORDS = CHAIN_SHARDS * CHAIN_SHARD_WORDS;  // counter words per task
+struct ChainWait {
+  const unsigned* cnt;  // the predecessor task's arrival counters (CHAIN_SHARDS shards); nullptr: nothing to wait for
+  unsigned gen1;        // generation + 1
+  int pred_nwg;         // workgroups of the predecessor task
+  unsigned* err;        // sticky error word (a poll ran into its deadline)
+  // diagnostic run only (tl_chain_set_stamps): 8 realtime stamps (100 MHz) of this workgroup, written by thread 0:
+  // [0] entry, [1] first weight loads issued, [2] predecessor seen, [3] x staged, [4] last loads issued, [5] all stores
+  // acknowledged and the workgroup met, [6] arrival added
+  unsigned long long* st;
+};
+__device__ __forceinline__ void chain_stamp(const ChainWait* cw, int k) {
+  if (cw->st != nullptr && threadIdx.x == 0) cw->st[k] = __builtin_amdgcn_s_memrealtime();
+}
+constexpr unsigned long long CHAIN_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz realtime counter
+
+__device__ __forceinline__ void chain_wait(const ChainWait& cw, int wave, int lane) {
+  if (cw.cnt == nullptr) return;  // (uniform)
+  if (wave == 0) {
+    const int sh = lane & (CHAIN_SHARDS - 1);
+    const unsigned want = cw.gen1 * (unsigned)((cw.pred_nwg + CHAIN_SHARDS - 1 - sh) / CHAIN_SHARDS);
+    const unsigned* p = cw.cnt + sh * CHAIN_SHARD_WORDS;
+    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + CHAIN_TIMEOUT_TICKS;
+    for (unsigned it = 1;; ++it) {
+      const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_load_dword sc1
+      const bool ok = (int)(v - want) >= 0;
+      if (__builtin_amdgcn_ballot_w64(ok) == ~0ull) break;
+      if ((it & 255u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) {
+        if (lane == 0) atomicOr(cw.err, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+// activation loads / stores across a task edge: sc1 (agent scope) in a chain launch, the ordinary forms otherwise
+template <bool CHAIN>
+__device__ __forceinline__ f32x4 ldx4(const void* base, unsigned byte_off) {
+  if constexpr (CHAIN) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 1 << 4));  // sc1
+  } else {
+    return ldc<f32x4>(base, byte_off);
+  }
+}
+template <bool CHAIN>
+__device__ __forceinline__ float ldx1(const float* p) {
+  if constexpr (CHAIN) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return ldg_f32(p);
+}
+template <bool CHAIN>
+__device__ __forceinline__ void stx1(float* p, float v) {
+  if constexpr (CHAIN) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else stg_f32(p, v);
+}
 
 // ---- x staging: (optional RMSNorm, utils.cpp:648-673) -> strided LDS image + per-chunk half sums --------------
 // Split in two so that the x loads are the FIRST loads a wave issues: loads return in order, and staging must not
@@ -98,7 +172,7 @@ __device__ __forceinline__ void xattn_fold(int s0, int active, const f32x4* ao, 
 }
 // Unconditional (index-clamped) loads: a load under a branch makes the compiler wait with vmcnt(0) at the join,
 // which would also wait for the weight loads issued after these.
-template <bool XATTN>
+template <bool XATTN, bool CHAIN = false>
 __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
   const int n4 = a.cols >> 2;
   if (XATTN) {
@@ -113,7 +187,7 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int i = threadIdx.x + k * a.nthr;
-    r.v[k] = ldc<f32x4>(a.x, (unsigned)(i < n4 ? i : n4 - 1) * 16u);
+    r.v[k] = ldx4<CHAIN>(a.x, (unsigned)(i < n4 ? i : n4 - 1) * 16u);
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -122,7 +196,7 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
   }
 }
 __device__ __forceinline__ float ssq4(f32x4 t) { return (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]); }
-template <bool XATTN>
+template <bool XATTN, bool CHAIN = false>
 __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r, float* smem) {
   float* xs = smem + XS_SCRATCH;
   const int tid = threadIdx.x, nthr = a.nthr;
@@ -165,7 +239,7 @@ __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r,
     float ssq = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) ssq += (tid + k * nthr < n4) ? ssq4(r.v[k]) : 0.f;
-    for (int i = tid + 4 * nthr; i < n4; i += nthr) ssq += ssq4(x4[i]);
+    for (int i = tid + 4 * nthr; i < n4; i += nthr) ssq += ssq4(CHAIN ? ldx4<CHAIN>(a.x, (unsigned)i * 16u) : x4[i]);
     ssq = wave_sum_lane63(ssq);  // DPP only (the xor butterfly is six dependent LDS-path shuffles here)
     if ((tid & 63) == 63) smem[tid >> 6] = ssq;
     __syncthreads();
@@ -193,7 +267,7 @@ __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r,
     const int i = tid + k * nthr;
     if (i < n4) put(i, r.v[k], k < 2 ? r.g[k] : (a.norm_w ? w4[i] : one));
   }
-  for (int i = tid + 4 * nthr; i < n4; i += nthr) put(i, x4[i], a.norm_w ? w4[i] : one);
+  for (int i = tid + 4 * nthr; i < n4; i += nthr) put(i, CHAIN ? ldx4<CHAIN>(a.x, (unsigned)i * 16u) : x4[i], a.norm_w ? w4[i] : one);
   __syncthreads();
 }
 
@@ -328,10 +402,12 @@ struct StepMeta {
 // vmcnt that leaves the prefetch in flight.
 // RESID: out[r] = resid[r] + y[r]. The two residual values are loaded at ISSUE time, ahead of the step's weight loads:
 // loads complete in order, so a load in the epilogue would drain the whole prefetch queue once per row group.
-template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP, bool PEER = false>
-__device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const XRegs& xr, float* smem, int first,
+// CHAIN (a task of a chain launch): x and the first residual values are loaded only AFTER the wait for the predecessor
+// task, which follows the first weight loads; activation loads and stores take their sc1 forms.
+template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP, bool PEER = false, bool CHAIN = false>
+__device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, XRegs& xr, float* smem, int first,
                                           int stride, int total, int lane, unsigned long long* ts, unsigned pe = 0,
-                                          int peer_wave = 0) {
+                                          int peer_wave = 0, const ChainWait* cw = nullptr) {
   const float* xs = smem + XS_SCRATCH;
   const int nchunks = a.cols >> 5;
   const int nspans = (nchunks + 63) >> 6;
@@ -340,7 +416,11 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   int ndone = 0;
   if (first >= total) {  // a wave without work only helps staging x
     if (STAMP) ts[3] = __builtin_readcyclecounter();
-    stage_x_finish<XATTN>(a, xr, smem);
+    if constexpr (CHAIN) {
+      chain_wait(*cw, peer_wave, lane);
+      stage_x_issue<XATTN, CHAIN>(a, xr);
+    }
+    stage_x_finish<XATTN, CHAIN>(a, xr, smem);
     if (STAMP) ts[4] = __builtin_readcyclecounter();
     return;
   }
@@ -350,6 +430,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   float* out = g.o0;
   group_of<PAIR>(g, irg, wa, wb, ra, rb, out);
   float acc0 = 0.f, acc1 = 0.f;
+  bool with_resid = !CHAIN;  // (CHAIN: the first step's residual values follow the wait)
 
   auto issue = [&](Step<TYPE>& st, StepMeta& m) {
     m.sp = isp;
@@ -358,9 +439,9 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
     m.out = out;
     const int chunk = (isp << 6) + lane;
     const unsigned cc = chunk < nchunks ? chunk : nchunks - 1;
-    if (RESID) {
-      st.r0 = ldg_f32(a.resid + ra);
-      st.r1 = ldg_f32(a.resid + rb);
+    if (RESID && (!CHAIN || with_resid)) {
+      st.r0 = ldx1<CHAIN>(a.resid + ra);
+      st.r1 = ldx1<CHAIN>(a.resid + rb);
     }
     st.c0.load(wa, ra, cc);
     st.c1.load(wb, rb, cc);
@@ -392,7 +473,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
       if (lane == 63) {
         if (PAIR) {
           const float sg = 1.0f / (1.0f + expf(-y0));  // silu_cpu (utils.cpp:700-707), then * up (model.cpp:735)
-          stg_f32(m.out + m.ra, (y0 * sg) * y1);
+          stx1<CHAIN>(m.out + m.ra, (y0 * sg) * y1);
         } else if (PEER) {  // into the wave's stash; pushed and collected at the end of the wave's work (peer_collect)
           stash[2 * ndone] = RESID ? st.r0 + y0 : y0;
           stash[2 * ndone + 1] = RESID ? st.r1 + y1 : y1;
@@ -401,8 +482,8 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
             if (m.ra + 1 < m.rows) stg_f32(m.out + m.ra + 1, y1);
           }
         } else {
-          stg_f32(m.out + m.ra, RESID ? st.r0 + y0 : y0);
-          if (m.ra + 1 < m.rows) stg_f32(m.out + m.ra + 1, RESID ? st.r1 + y1 : y1);
+          stx1<CHAIN>(m.out + m.ra, RESID ? st.r0 + y0 : y0);
+          if (m.ra + 1 < m.rows) stx1<CHAIN>(m.out + m.ra + 1, RESID ? st.r1 + y1 : y1);
         }
       }
       acc0 = 0.f;
@@ -415,13 +496,26 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
   // named buffers instead of the copy makes hipcc insert vmcnt(0) waits in front of unrelated register writes.)
   Step<TYPE> cur, nxt;
   StepMeta mc, mn;
+  const int ra0 = ra, rb0 = rb;
   issue(cur, mc);  // the first step's loads go out before x is staged: the HBM round trip overlaps the prologue
   // (Issuing a SECOND step ahead of the staging was tried twice and measured slower both times: in this loop the copy
   //  form then waits for its own fresh loads, -10 %; as a loop-free variant for the launches with two steps per wave,
   //  attn_output and QKV, -1.7 %: the x loads of the waves that start late queue behind twice as many weight loads of
   //  the early ones, and staging ends with a barrier.)
   if (STAMP) ts[3] = __builtin_readcyclecounter();
-  stage_x_finish<XATTN>(a, xr, smem);
+  if constexpr (CHAIN) {  // the predecessor task's output exists from here on
+    chain_stamp(cw, 1);
+    chain_wait(*cw, peer_wave, lane);
+    chain_stamp(cw, 2);
+    stage_x_issue<XATTN, CHAIN>(a, xr);
+    if (RESID) {
+      cur.r0 = ldx1<CHAIN>(a.resid + ra0);
+      cur.r1 = ldx1<CHAIN>(a.resid + rb0);
+    }
+    with_resid = true;
+  }
+  stage_x_finish<XATTN, CHAIN>(a, xr, smem);
+  if constexpr (CHAIN) chain_stamp(cw, 3);
   if (STAMP) ts[4] = __builtin_readcyclecounter();
   while (irg < total) {
     issue(nxt, mn);
@@ -431,6 +525,7 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, const
     mc = mn;
   }
   if (STAMP) ts[6] = __builtin_readcyclecounter();  // every load of this wave has been issued
+  if constexpr (CHAIN) chain_stamp(cw, 4);
   consume(cur, mc);
   if (STAMP && ts[5] == 0) ts[5] = __builtin_readcyclecounter();
   if (PEER) peer_collect<RESID>(a.peer, pe, g.o0, g.w0.rows, first, stride, ndone, stash, lane);
@@ -607,13 +702,15 @@ __device__ __forceinline__ void run_class_flat(const Segs& g, const GemvVec& a, 
 // RA > 0: the flattened step scheme above with RA rows per stream and group (the host sizes t0..t2 accordingly).
 // PEER: the launch carries its tensor-parallel exchange (a.peer; single matrix, RA = 0): all-reduce for the residual roles,
 // all-gather otherwise.
-template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false>
-__global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
-                                                                int t0, int t1, int t2, int nsegA, int wavesA) {
+// The body of a launch; `bid` is the workgroup's index among the a.grid workgroups of the launch (blockIdx.x), or of its
+// task in a chain launch (CHAIN; cw says what to wait for; RA = 0, no PEER).
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false, bool CHAIN = false>
+__device__ __forceinline__ void gemv_body(const GemvSeg& sg0, const GemvSeg& sg1, const GemvSeg& sg2, const GemvVec& a,
+                                          int t0, int t1, int t2, int nsegA, int wavesA, int bid, float* smem,
+                                          const ChainWait* cw = nullptr) {
   // the roles launched with a residual / with x still in attention partials
   constexpr bool RESID = ROLE == GEMV_ATTN_OUT || ROLE == GEMV_DOWN || ROLE == GEMV_ATTN_OUT_COMBINE;
   constexpr bool XATTN = ROLE == GEMV_ATTN_OUT_COMBINE;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
   unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0}, rt0 = 0;
   if (STAMP) {
     ts[0] = __builtin_readcyclecounter();
@@ -637,7 +734,7 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nwaves = a.nthr >> 6;
   XRegs xr;
-  stage_x_issue<XATTN>(a, xr);
+  if constexpr (!CHAIN) stage_x_issue<XATTN>(a, xr);  // (CHAIN: after the wait for the predecessor task, in run_class)
   if (STAMP) ts[2] = __builtin_readcyclecounter();
   unsigned pe = 0;  // the epoch this launch's words carry: one more than the exchanges completed (0 = cleared area)
   if (PEER) {
@@ -649,21 +746,21 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
     const int total = PAIR ? t0 : (nsegA == 1 ? t0 : (nsegA == 2 ? t0 + t1 : t0 + t1 + t2));
     const Segs g = {sg0.w, sg1.w, sg2.w, sg0.out, sg1.out, sg2.out, t0, nsegA >= 2 ? t1 : 0x3fffffff};
     if constexpr (RA > 0)
-      run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane);
+      run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * a.grid + bid, a.grid * wA, total, lane);
     else
-      run_class<TA, PAIR, RESID, XATTN, STAMP, PEER>(g, a, xr, smem, wave * a.grid + blockIdx.x, a.grid * wA, total, lane,
-                                                     ts, pe, wave);
+      run_class<TA, PAIR, RESID, XATTN, STAMP, PEER, CHAIN>(g, a, xr, smem, wave * a.grid + bid, a.grid * wA, total, lane,
+                                                            ts, pe, wave, cw);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
     const int tb = nsegA == 1 ? t1 : t2;
     const Segs g = {sb.w, sb.w, sb.w, sb.out, sb.out, sb.out, 0x3fffffff, 0x3fffffff};
     if constexpr (RA > 0)
-      run_class_flat<TBB, false, false, XATTN, RA>(g, a, xr, smem, (wave - wavesA) * a.grid + blockIdx.x,
+      run_class_flat<TBB, false, false, XATTN, RA>(g, a, xr, smem, (wave - wavesA) * a.grid + bid,
                                                    a.grid * (nwaves - wavesA), tb, lane);
     else
-      run_class<TBB, false, false, XATTN, STAMP>(g, a, xr, smem, (wave - wavesA) * a.grid + blockIdx.x,
-                                                 a.grid * (nwaves - wavesA), tb, lane, ts);
+      run_class<TBB, false, false, XATTN, STAMP, false, CHAIN>(g, a, xr, smem, (wave - wavesA) * a.grid + bid,
+                                                               a.grid * (nwaves - wavesA), tb, lane, ts, 0, wave, cw);
   }
   if (PEER) {  // every wave has read the epoch and collected its rows: the last workgroup through advances the epoch
     __syncthreads();
@@ -677,10 +774,99 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
   }
   if (STAMP && lane == 0 && ts[5] != 0) {
     ts[7] = __builtin_readcyclecounter();
-    unsigned long long* o = a.stamps + 10 * (size_t)(wave * a.grid + blockIdx.x);
+    unsigned long long* o = a.stamps + 10 * (size_t)(wave * a.grid + bid);
     for (int i = 0; i < 8; ++i) o[i] = ts[i];
     o[8] = __builtin_amdgcn_s_memrealtime();
     o[9] = rt0;
+  }
+}
+
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false>
+__global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, GemvSeg sg1, GemvSeg sg2, GemvVec a,
+                                                                int t0, int t1, int t2, int nsegA, int wavesA) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  gemv_body<TA, TB, PAIR, ROLE, STAMP, RA, PEER>(sg0, sg1, sg2, a, t0, t1, t2, nsegA, wavesA, blockIdx.x, smem);
+}
+
+// ---- the chain launch: grid (workgroups per task, tasks); every workgroup runs the body its task names -------------------
+struct alignas(128) ChainTask {
+  GemvSeg sg[3];
+  GemvVec a;
+  int t[3];
+  int nsegA, wavesA;
+  int code;      // chain_code(): role and format(s) of the body
+  int nwg;       // workgroups of this task that work (the others of the row leave at once)
+  int pred_nwg;  // ... of the task before it in the launch (0: first task, nothing to wait for)
+  int pad;
+};
+static_assert(sizeof(ChainTask) == TL_CHAIN_TASK_BYTES, "TL_CHAIN_TASK_BYTES (tl_internal.h) is the stride of a task array");
+constexpr int CHAIN_ROLE_QKV = 0, CHAIN_ROLE_COMBINE = 1, CHAIN_ROLE_GATE_UP = 2, CHAIN_ROLE_DOWN = 3, CHAIN_ROLE_LM_HEAD = 4;
+constexpr int CHAIN_QKV_MIXED = 3;  // type slot of the Q4_K + Q6_K launch
+__host__ __device__ constexpr int chain_code(int role, int tslot) { return role * 4 + tslot; }
+static int chain_type_slot(int type) { return type == TL_Q4_K ? 0 : type == TL_Q6_K ? 1 : type == TL_Q8_0 ? 2 : -1; }
+
+template <int TA, int TB, bool PAIR, int ROLE>
+__device__ __forceinline__ void chain_body(const ChainTask& T, int bid, float* smem, const ChainWait* cw) {
+  gemv_body<TA, TB, PAIR, ROLE, false, 0, false, true>(T.sg[0], T.sg[1], T.sg[2], T.a, T.t[0], T.t[1], T.t[2], T.nsegA,
+                                                       T.wavesA, bid, smem, cw);
+}
+
+// Persistent form: ONE workgroup of 16 waves per CU walks through the launch's tasks. A wave that has finished its rows
+// of task j drains its stores, adds itself to the workgroup's LDS counter (the last one adds the workgroup's arrival to
+// the task's counter) and goes straight on to task j + 1: descriptor, first weight loads, and only then the workgroup
+// barrier behind which the predecessor is polled for and x is staged -- so the tail of a task (its slowest waves, ~3 us)
+// is covered by the next task's first HBM round trip, wave by wave, and no workgroup ever leaves or enters a CU between
+// tasks. Every wave passes the same barriers in the same order (waves without rows only help staging), and the barrier
+// of task j + 1's wait is also what makes the x image in LDS free to overwrite.
+__global__ __launch_bounds__(GEMV_MAX_THREADS) void chain_kernel(const ChainTask* __restrict__ tasks, int ntasks,
+                                                                 unsigned* sync, const unsigned* __restrict__ gen,
+                                                                 unsigned* err, unsigned long long* stamps, int stamp_stride) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // the workgroup's count of waves that are through with a task: the last word of the reduction scratch in front of the x
+  // image, which no chain body uses (a static __shared__ variable would come off the 160 KiB the x image may take)
+  unsigned& wg_waves_done = *(reinterpret_cast<unsigned*>(smem) + (XS_SCRATCH - 1));
+  const int bid = blockIdx.x;
+  if (threadIdx.x == 0) wg_waves_done = 0u;
+  __syncthreads();
+  const unsigned gen1 = *gen + 1u;
+  unsigned served = 0;  // tasks this workgroup has worked on
+  for (int task = 0; task < ntasks; ++task) {
+    const ChainTask T = tasks[task];  // (uniform address, read-only: scalar loads)
+    if (bid >= T.nwg) continue;       // (uniform over the workgroup)
+    unsigned long long* st = stamps ? stamps + 8 * ((size_t)task * stamp_stride + bid) : nullptr;
+    const ChainWait cw = {T.pred_nwg > 0 ? sync + (size_t)(task - 1) * CHAIN_TASK_WORDS : nullptr, gen1, T.pred_nwg, err, st};
+    chain_stamp(&cw, 0);
+    switch (T.code) {
+      case chain_code(CHAIN_ROLE_QKV, 0): chain_body<TL_Q4_K, TL_NONE, false, GEMV_QKV>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_QKV, 1): chain_body<TL_Q6_K, TL_NONE, false, GEMV_QKV>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_QKV, 2): chain_body<TL_Q8_0, TL_NONE, false, GEMV_QKV>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_QKV, CHAIN_QKV_MIXED): chain_body<TL_Q4_K, TL_Q6_K, false, GEMV_QKV>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_COMBINE, 0): chain_body<TL_Q4_K, TL_NONE, false, GEMV_ATTN_OUT_COMBINE>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_COMBINE, 1): chain_body<TL_Q6_K, TL_NONE, false, GEMV_ATTN_OUT_COMBINE>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_COMBINE, 2): chain_body<TL_Q8_0, TL_NONE, false, GEMV_ATTN_OUT_COMBINE>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_GATE_UP, 0): chain_body<TL_Q4_K, TL_NONE, true, GEMV_GATE_UP>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_GATE_UP, 1): chain_body<TL_Q6_K, TL_NONE, true, GEMV_GATE_UP>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_GATE_UP, 2): chain_body<TL_Q8_0, TL_NONE, true, GEMV_GATE_UP>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_DOWN, 0): chain_body<TL_Q4_K, TL_NONE, false, GEMV_DOWN>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_DOWN, 1): chain_body<TL_Q6_K, TL_NONE, false, GEMV_DOWN>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_DOWN, 2): chain_body<TL_Q8_0, TL_NONE, false, GEMV_DOWN>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_LM_HEAD, 0): chain_body<TL_Q4_K, TL_NONE, false, GEMV_LM_HEAD>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_LM_HEAD, 1): chain_body<TL_Q6_K, TL_NONE, false, GEMV_LM_HEAD>(T, bid, smem, &cw); break;
+      case chain_code(CHAIN_ROLE_LM_HEAD, 2): chain_body<TL_Q8_0, TL_NONE, false, GEMV_LM_HEAD>(T, bid, smem, &cw); break;
+      default: break;
+    }
+    // this wave's stores have been acknowledged; the last wave of the workgroup to get here adds the workgroup's arrival
+    ++served;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) {
+      const unsigned before = __hip_atomic_fetch_add(&wg_waves_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (before + 1u == served * (unsigned)(GEMV_MAX_THREADS / 64)) {
+        if (st) st[5] = __builtin_amdgcn_s_memrealtime();
+        __hip_atomic_fetch_add(sync + (size_t)task * CHAIN_TASK_WORDS + (bid & (CHAIN_SHARDS - 1)) * CHAIN_SHARD_WORDS, 1u,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st) st[6] = __builtin_amdgcn_s_memrealtime();
+      }
+    }
   }
 }
 
@@ -825,7 +1011,11 @@ static int gemv_geometry(Launch& L, int total) {
   return waves;
 }
 
-int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
+// Plans a fused launch: geometry, row groups, format classes. *plain = false: the arguments need one of the unfused routes
+// of tl_launch_gemv (F32 matrices, a gate/up pair in two formats, other format mixtures) and L is not filled in.
+// role_out: the instantiation (GemvRole); classB_out: Q4_K segments followed by one Q6_K segment.
+static int gemv_plan(const GemvArgs& a, Launch& L, int* role_out, bool* classB_out, bool* plain) {
+  *plain = false;
   TL_TRY(gemv_setup());
   TL_REQUIRE(a.nseg >= 1 && a.nseg <= 3, "gemv: nseg %d", a.nseg);
   TL_REQUIRE(a.cols > 0 && a.cols % 32 == 0, "gemv: cols %d must be a positive multiple of 32", a.cols);
@@ -836,20 +1026,9 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   if (a.pair)
     TL_REQUIRE(a.nseg == 2 && a.seg[0].w.rows == a.seg[1].w.rows, "gemv: pair mode needs two equal-shaped matrices");
   TL_REQUIRE(!a.resid || a.nseg == 1, "gemv: residual epilogue needs a single matrix");
-  bool any_f32 = false;
-  for (int i = 0; i < a.nseg; ++i) any_f32 |= a.seg[i].w.type == TL_F32;
-  if (any_f32) {
-    TL_REQUIRE(!a.pair && !a.norm_w && !a.peer, "gemv: F32 matrices are not supported in fused launches");
-    for (int i = 0; i < a.nseg; ++i) {
-      TL_REQUIRE(a.seg[i].w.type == TL_F32, "gemv: mixed F32 / quantized segments are not supported");
-      const QW& w = a.seg[i].w;
-      gemv_f32_kernel<<<(w.rows + 3) / 4, 256, 0, s>>>(reinterpret_cast<const float*>(w.p0), a.x, a.resid,
-                                                        a.seg[i].out, w.rows, w.cols);
-    }
-    TL_HIP(hipGetLastError());
-    return 0;
-  }
-  Launch L = {};
+  for (int i = 0; i < a.nseg; ++i)
+    if (a.seg[i].w.type == TL_F32) return 0;
+  L = Launch{};
   L.lds = sizeof(float) * (XS_SCRATCH + (size_t)(a.cols / 32) * XS_STRIDE);
   TL_REQUIRE(L.lds <= 160 * 1024, "gemv: cols %d needs %zu B of LDS (> 160 KiB)", a.cols, L.lds);
   L.v = GemvVec{a.x, a.norm_w, a.resid, a.eps, a.cols, nullptr, a.attn_ws, a.attn_pos, a.attn_hd, a.attn_merged, 0, 0, a.peer, 0};
@@ -863,46 +1042,21 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   long total_rows = 0;
   for (int i = 0; i < (a.pair ? 1 : a.nseg); ++i) total_rows += a.seg[i].w.rows;
   L.ra = a.peer ? 0 : gemv_flat_rows(a.cols, flat_ok, total_rows, a.pair != 0);  // (the collect phase walks span row groups)
-
+  *classB_out = false;
   if (a.pair) {
-    if (a.seg[1].w.type != ta) {
-      // gate and up in different formats (not produced by any mix the reference loads): two launches + SwiGLU.
-      // The up projection goes through a.seg[1].out, which the caller must then provide.
-      TL_REQUIRE(a.seg[1].out, "gemv: a mixed-format gate/up pair needs a scratch output for the up projection");
-      GemvArgs g1 = a, g2 = a;
-      g1.pair = g2.pair = 0;
-      g1.nseg = g2.nseg = 1;
-      g2.seg[0] = a.seg[1];
-      g1.role = g2.role = GEMV_GENERIC;
-      TL_TRY(tl_launch_gemv(g1, s));
-      TL_TRY(tl_launch_gemv(g2, s));
-      const int n = a.seg[0].w.rows;
-      swiglu_inplace_kernel<<<(n + 255) / 256, 256, 0, s>>>(a.seg[0].out, a.seg[1].out, n);
-      TL_HIP(hipGetLastError());
-      return 0;
-    }
+    if (a.seg[1].w.type != ta) return 0;  // gate and up in different formats: unfused
     L.t[0] = L.ra ? (a.seg[0].w.rows + L.ra - 1) / L.ra : a.seg[0].w.rows;
     L.nsegA = 2;
-    gemv_geometry(L, L.t[0]);
-    TL_TRY(gemv_launch_pair(ta, L, s));
-    TL_HIP(hipGetLastError());
+    L.wavesA = gemv_geometry(L, L.t[0]);
+    *role_out = GEMV_GATE_UP;
+    *plain = true;
     return 0;
   }
-
   // format classes: segments [0, nsegA) share seg[0]'s format; at most ONE trailing segment may differ
   int nsegA = 1;
   while (nsegA < a.nseg && a.seg[nsegA].w.type == ta) ++nsegA;
   const bool classB = nsegA < a.nseg;
-  if (classB && !(nsegA == a.nseg - 1 && ta == TL_Q4_K && a.seg[nsegA].w.type == TL_Q6_K)) {
-    // any other mixture: one launch per segment (correct, just not fused)
-    for (int i = 0; i < a.nseg; ++i) {
-      GemvArgs one = a;
-      one.nseg = 1;
-      one.seg[0] = a.seg[i];
-      TL_TRY(tl_launch_gemv(one, s));
-    }
-    return 0;
-  }
+  if (classB && !(nsegA == a.nseg - 1 && ta == TL_Q4_K && a.seg[nsegA].w.type == TL_Q6_K)) return 0;  // other mixtures
   double bytesA = 0.0, bytesB = 0.0;
   int totalA = 0;
   for (int i = 0; i < a.nseg; ++i) {
@@ -926,16 +1080,16 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
     TL_REQUIRE(L.lds <= 160 * 1024, "gemv: %d row groups per wave do not fit the LDS stash of a launch that carries its exchange",
                L.v.peer_gpw);
   }
+  *classB_out = classB;
   if (classB) {
     int wa = (int)(waves * bytesA / (bytesA + bytesB) + 0.5);
     if (wa < 1) wa = 1;
     if (wa > waves - 1) wa = waves - 1;
     L.wavesA = wa;
-    TL_TRY((gemv_launch_one<TL_Q4_K, TL_Q6_K, false, GEMV_QKV>(L, s)));
-    TL_HIP(hipGetLastError());
+    *role_out = GEMV_QKV;
+    *plain = true;
     return 0;
   }
-  int rc = 0;
   int role = a.role;  // the residual epilogue is compiled into the ATTN_OUT / DOWN instantiations only
   if (a.resid && role != GEMV_ATTN_OUT && role != GEMV_DOWN) role = GEMV_ATTN_OUT;
   if (!a.resid && (role == GEMV_ATTN_OUT || role == GEMV_DOWN)) role = GEMV_GENERIC;
@@ -945,15 +1099,155 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
                "gemv: attention-partials input needs a single residual launch without norm");
     role = GEMV_ATTN_OUT_COMBINE;
   }
-  switch (role) {
-    case GEMV_ATTN_OUT_COMBINE: rc = gemv_launch_type<GEMV_ATTN_OUT_COMBINE>(ta, L, s); break;
-    case GEMV_QKV: rc = gemv_launch_type<GEMV_QKV>(ta, L, s); break;
-    case GEMV_ATTN_OUT: rc = gemv_launch_type<GEMV_ATTN_OUT>(ta, L, s); break;
-    case GEMV_DOWN: rc = gemv_launch_type<GEMV_DOWN>(ta, L, s); break;
-    case GEMV_LM_HEAD: rc = gemv_launch_type<GEMV_LM_HEAD>(ta, L, s); break;
-    default: rc = gemv_launch_type<GEMV_GENERIC>(ta, L, s); break;
+  *role_out = role;
+  *plain = true;
+  return 0;
+}
+
+int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
+  Launch L;
+  int role = GEMV_GENERIC;
+  bool classB = false, plain = false;
+  TL_TRY(gemv_plan(a, L, &role, &classB, &plain));
+  const int ta = a.seg[0].w.type;
+  if (!plain) {
+    bool any_f32 = false;
+    for (int i = 0; i < a.nseg; ++i) any_f32 |= a.seg[i].w.type == TL_F32;
+    if (any_f32) {
+      TL_REQUIRE(!a.pair && !a.norm_w && !a.peer, "gemv: F32 matrices are not supported in fused launches");
+      for (int i = 0; i < a.nseg; ++i) {
+        TL_REQUIRE(a.seg[i].w.type == TL_F32, "gemv: mixed F32 / quantized segments are not supported");
+        const QW& w = a.seg[i].w;
+        gemv_f32_kernel<<<(w.rows + 3) / 4, 256, 0, s>>>(reinterpret_cast<const float*>(w.p0), a.x, a.resid,
+                                                          a.seg[i].out, w.rows, w.cols);
+      }
+      TL_HIP(hipGetLastError());
+      return 0;
+    }
+    if (a.pair) {
+      // gate and up in different formats (not produced by any mix the reference loads): two launches + SwiGLU.
+      // The up projection goes through a.seg[1].out, which the caller must then provide.
+      TL_REQUIRE(a.seg[1].out, "gemv: a mixed-format gate/up pair needs a scratch output for the up projection");
+      GemvArgs g1 = a, g2 = a;
+      g1.pair = g2.pair = 0;
+      g1.nseg = g2.nseg = 1;
+      g2.seg[0] = a.seg[1];
+      g1.role = g2.role = GEMV_GENERIC;
+      TL_TRY(tl_launch_gemv(g1, s));
+      TL_TRY(tl_launch_gemv(g2, s));
+      const int n = a.seg[0].w.rows;
+      swiglu_inplace_kernel<<<(n + 255) / 256, 256, 0, s>>>(a.seg[0].out, a.seg[1].out, n);
+      TL_HIP(hipGetLastError());
+      return 0;
+    }
+    // any other format mixture: one launch per segment (correct, just not fused)
+    for (int i = 0; i < a.nseg; ++i) {
+      GemvArgs one = a;
+      one.nseg = 1;
+      one.seg[0] = a.seg[i];
+      TL_TRY(tl_launch_gemv(one, s));
+    }
+    return 0;
+  }
+  int rc = 0;
+  if (a.pair) {
+    rc = gemv_launch_pair(ta, L, s);
+  } else if (classB) {
+    rc = gemv_launch_one<TL_Q4_K, TL_Q6_K, false, GEMV_QKV>(L, s);
+  } else {
+    switch (role) {
+      case GEMV_ATTN_OUT_COMBINE: rc = gemv_launch_type<GEMV_ATTN_OUT_COMBINE>(ta, L, s); break;
+      case GEMV_QKV: rc = gemv_launch_type<GEMV_QKV>(ta, L, s); break;
+      case GEMV_ATTN_OUT: rc = gemv_launch_type<GEMV_ATTN_OUT>(ta, L, s); break;
+      case GEMV_DOWN: rc = gemv_launch_type<GEMV_DOWN>(ta, L, s); break;
+      case GEMV_LM_HEAD: rc = gemv_launch_type<GEMV_LM_HEAD>(ta, L, s); break;
+      default: rc = gemv_launch_type<GEMV_GENERIC>(ta, L, s); break;
+    }
   }
   TL_TRY(rc);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- chain launches: host side -------------------------------------------------------------------------------------------
+static unsigned long long* g_chain_stamps = nullptr;
+static size_t g_chain_stamps_cap = 0, g_chain_stamps_used = 0;
+// tl_chain_plan turns the arguments of one fused launch into a task of a chain launch (*ok = false: this launch has no chain
+// form -- an unfused route, flattened steps, a format without a chain body, a carried exchange); tasks of one chain are
+// uploaded by the caller (device array of ChainTask, TL_CHAIN_TASK_BYTES each) and run by tl_launch_chain.
+int tl_chain_plan(const GemvArgs& a, void* task_out, size_t* lds_out, int pred_nwg, int* nwg_out, bool* ok) {
+  *ok = false;
+  Launch L;
+  int role = GEMV_GENERIC;
+  bool classB = false, plain = false;
+  TL_TRY(gemv_plan(a, L, &role, &classB, &plain));
+  if (!plain || L.ra != 0 || a.peer) return 0;
+  int crole = -1;
+  switch (role) {
+    case GEMV_QKV: crole = CHAIN_ROLE_QKV; break;
+    case GEMV_ATTN_OUT_COMBINE: crole = CHAIN_ROLE_COMBINE; break;
+    case GEMV_GATE_UP: crole = CHAIN_ROLE_GATE_UP; break;
+    case GEMV_DOWN: crole = CHAIN_ROLE_DOWN; break;
+    case GEMV_LM_HEAD: crole = CHAIN_ROLE_LM_HEAD; break;
+    default: return 0;
+  }
+  const int slot = classB ? CHAIN_QKV_MIXED : chain_type_slot(a.seg[0].w.type);
+  if (slot < 0) return 0;
+  ChainTask t = {};
+  for (int i = 0; i < 3; ++i) {
+    t.sg[i] = L.seg[i];
+    t.t[i] = L.t[i];
+  }
+  t.a = L.v;
+  // every wave of the persistent workgroup takes part in every task (same barriers for all). A launch of its own with
+  // fewer waves has at most one row group per wave, and wave w takes the same one here (the others only help staging
+  // x); a row's sum does not depend on the wave that forms it
+  t.a.nthr = GEMV_MAX_THREADS;
+  t.a.grid = L.grid;
+  t.nsegA = L.nsegA;
+  t.wavesA = L.wavesA;
+  t.code = chain_code(crole, slot);
+  t.nwg = L.grid;
+  t.pred_nwg = pred_nwg;
+  memcpy(task_out, &t, sizeof(t));
+  *lds_out = L.lds;
+  *nwg_out = L.grid;
+  *ok = true;
+  return 0;
+}
+
+// tasks_dev: ntasks ChainTask records (TL_CHAIN_TASK_BYTES each, 128-byte aligned); sync: ntasks * CHAIN_TASK_WORDS
+// counter words of THIS launch (zero at allocation, never reset); gen: the generation word; err: the sticky error word
+int tl_launch_chain(const void* tasks_dev, int ntasks, int max_nwg, size_t lds, unsigned* sync, const unsigned* gen,
+                    unsigned* err, hipStream_t s) {
+  TL_REQUIRE(tasks_dev && ntasks > 0 && max_nwg > 0 && sync && gen && err, "tl_launch_chain: bad argument");
+  static TlDeviceOnce lds_raised;
+  TL_TRY(tl_raise_lds_limit(chain_kernel, 160 * 1024, lds_raised));
+  unsigned long long* st = g_chain_stamps;
+  if (st) {  // diagnostic run: consecutive launches fill consecutive regions of the buffer
+    if (g_chain_stamps_used + (size_t)ntasks * 256 * 8 > g_chain_stamps_cap) st = nullptr;
+    else {
+      st += g_chain_stamps_used;
+      g_chain_stamps_used += (size_t)ntasks * 256 * 8;
+    }
+  }
+  chain_kernel<<<max_nwg, GEMV_MAX_THREADS, lds, s>>>(static_cast<const ChainTask*>(tasks_dev), ntasks, sync, gen, err, st, 256);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+// Diagnostic hook (no counterpart in the reference): from now on every chain launch writes 8 realtime stamps per workgroup
+// (ChainWait::st) into buf_dev, [launch][task][256 workgroups][8] u64 in launch order, until cap_u64 words are used; nullptr
+// switches the stamps off. Launch eagerly (TL_NO_GRAPH=1): a captured graph keeps the pointer it was captured with.
+extern "C" int tl_chain_set_stamps(unsigned long long* buf_dev, size_t cap_u64) {
+  g_chain_stamps = buf_dev;
+  g_chain_stamps_cap = buf_dev ? cap_u64 : 0;
+  g_chain_stamps_used = 0;
+  return 0;
+}
+size_t tl_chain_sync_words(int ntasks) { return (size_t)ntasks * CHAIN_TASK_WORDS; }
+__global__ void chain_gen_bump_kernel(unsigned* gen) { *gen = *gen + 1u; }
+int tl_launch_chain_gen_bump(unsigned* gen, hipStream_t s) {
+  chain_gen_bump_kernel<<<1, 1, 0, s>>>(gen);
   TL_HIP(hipGetLastError());
   return 0;
 }

@@ -151,6 +151,14 @@ struct GemvArgs {
   const TlPeerDev* peer;
 };
 int tl_launch_gemv(const GemvArgs& a, hipStream_t s);
+// chain launches (tl_gemv.hip): several fused GEMV launches of the decode step as tasks of ONE launch, handed over through
+// arrival counters instead of kernel boundaries
+constexpr size_t TL_CHAIN_TASK_BYTES = 384;  // sizeof(ChainTask) (checked in tl_gemv.hip), the stride of a task array
+int tl_chain_plan(const GemvArgs& a, void* task_out, size_t* lds_out, int pred_nwg, int* nwg_out, bool* ok);
+int tl_launch_chain(const void* tasks_dev, int ntasks, int max_nwg, size_t lds, unsigned* sync, const unsigned* gen,
+                    unsigned* err, hipStream_t s);
+size_t tl_chain_sync_words(int ntasks);
+int tl_launch_chain_gen_bump(unsigned* gen, hipStream_t s);
 int tl_launch_prefetch(const void* p, size_t bytes, int blocks, unsigned* sink, hipStream_t s);
 
 int tl_launch_rmsnorm(const float* x, const float* w, float* out, int T, int n, float eps, int floor_eps,

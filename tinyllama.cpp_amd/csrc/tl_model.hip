@@ -122,6 +122,23 @@ struct tl_model {
     size_t ids_cap = 0;
     int gemv_max = 0;  // steps with at most this many sequences take the multi-vector GEMV route (0: never)
   } bt;
+  // Chain launches (tl_gemv.hip): the step's GEMVs between two attention launches -- attn_output, gate/up, ffn_down and the
+  // next layer's QKV (the lm_head after the last layer) -- run as tasks of ONE launch, handed over through arrival counters
+  // instead of kernel boundaries. Planned by tl_model_finalize for unsharded models whose launches all have a chain body;
+  // TL_CHAIN=0 keeps one launch per projection.
+  struct Chain {
+    bool on = false;
+    void* tasks = nullptr;     // device: the tasks of all chain launches, TL_CHAIN_TASK_BYTES each
+    unsigned* sync = nullptr;  // device: [generation word | error word | pad to 64 words | arrival counters of every task]
+    struct Launch {
+      int first_task, ntasks, max_nwg;
+      size_t lds;
+    };
+    std::vector<Launch> launches;  // launches[l]: behind the attention of layer l
+    unsigned* gen() const { return sync; }
+    unsigned* err() const { return sync + 1; }
+    unsigned* counters(int first_task) const { return sync + 64 + tl_chain_sync_words(first_task); }
+  } chain;
   int alt_seq = -1;  // >= 0: kc() / vc() address this sequence's region of the batch cache (prompt prefill of a sequence)
   float* kc(int l) const {
     return alt_seq >= 0 ? bt.kv + (((size_t)l * 2) * bt.max_batch + alt_seq) * kv_layer_elems
@@ -217,6 +234,8 @@ extern "C" int tl_model_free(tl_model* m) {
   hipFree(m->cand_i);
   hipFree(m->attn_ws);
   hipFree(m->xn);
+  hipFree(m->chain.tasks);
+  hipFree(m->chain.sync);
   float* pbufs[] = {m->pf.xb, m->pf.qb, m->pf.kb, m->pf.vb, m->pf.ab, m->pf.gb, m->pf.ub, m->pf.logits_all, m->pf.xpart,
                     m->pf.xb2, m->pf.part[0], m->pf.part[1], m->pf.part[2]};
   for (float* b : pbufs) hipFree(b);
@@ -601,13 +620,11 @@ static int enqueue_embed(tl_model* m, hipStream_t s) {
   // and as the prefill route (prefill_embed) does, instead of silently reading row 0
   return tl_launch_dequant_gather(m->tok, m->state, 1, m->x, s);
 }
-// norm + QKV GEMV, RoPE + KV write + attention, attn_output GEMV (-> x, or the partial xp when tp > 1)
-static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
+// RoPE + KV write + attention of layer l (split partials in attn_ws, or the output in att)
+static int enqueue_attention(tl_model* m, int l, hipStream_t s, StepProf* prof) {
   const tl_model_config& c = m->cfg;
   const int* pos_dev = m->state + 1;
   const float scale = 1.0f / sqrtf((float)m->head_dim);
-  TL_TRY(launch_proj(m, args_qkv(m, l), s));
-  PROF_MARK(1);
   if (m->attn_split) {  // RoPE + KV write + split attention in one launch
     AttnArgs t = {};
     t.q = m->q;
@@ -634,6 +651,13 @@ static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) 
     TL_TRY(tl_launch_attn_decode(m->q, m->kc(l), m->vc(l), m->att, m->nh_l, m->nkv_l, m->head_dim, 0, pos_dev,
                                  c.max_position_embeddings, scale, s));
   }
+  return 0;
+}
+// norm + QKV GEMV, RoPE + KV write + attention, attn_output GEMV (-> x, or the partial xp when tp > 1)
+static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
+  TL_TRY(launch_proj(m, args_qkv(m, l), s));
+  PROF_MARK(1);
+  TL_TRY(enqueue_attention(m, l, s, prof));
   PROF_MARK(3);
   return launch_proj(m, args_attn_out(m, l), s);
 }
@@ -657,8 +681,75 @@ static int enqueue_sample_topk(tl_model* m, hipStream_t s) {
                                m->sparams, nullptr, nullptr, nullptr, nullptr, s);
 }
 
+// The chain form of the step (tl_model::Chain): embed | QKV of layer 0 | per layer: attention, then ONE launch with the tasks
+// attn_output -> gate/up -> ffn_down -> next QKV (lm_head after the last layer) | sampling | generation bump.
+static int plan_chain(tl_model* m) {
+  m->chain.on = false;
+  if (const char* e = getenv("TL_CHAIN"))
+    if (atoi(e) == 0) return 0;
+  if (m->tp != 1 || m->comm || m->has_f32 || !m->attn_split) return 0;
+  const int L = m->cfg.num_hidden_layers;
+  std::vector<unsigned char> host((size_t)L * 4 * TL_CHAIN_TASK_BYTES, 0);
+  m->chain.launches.clear();
+  for (int l = 0; l < L; ++l) {
+    const GemvArgs args[4] = {args_attn_out(m, l), args_gate_up(m, l), args_down(m, l),
+                              l + 1 < L ? args_qkv(m, l + 1) : args_lm_head(m)};
+    tl_model::Chain::Launch cl = {l * 4, 4, 0, 0};
+    int pred = 0;
+    for (int j = 0; j < 4; ++j) {
+      size_t lds = 0;
+      int nwg = 0;
+      bool ok = false;
+      TL_TRY(tl_chain_plan(args[j], host.data() + (size_t)(l * 4 + j) * TL_CHAIN_TASK_BYTES, &lds, pred, &nwg, &ok));
+      if (!ok) return 0;  // a launch without a chain body: the whole model keeps one launch per projection
+      pred = nwg;
+      if (nwg > cl.max_nwg) cl.max_nwg = nwg;
+      if (lds > cl.lds) cl.lds = lds;
+    }
+    m->chain.launches.push_back(cl);
+  }
+  const size_t sync_bytes = sizeof(unsigned) * (64 + tl_chain_sync_words(L * 4));
+  TL_HIP(hipMalloc(&m->chain.tasks, host.size()));
+  TL_HIP(hipMalloc(&m->chain.sync, sync_bytes));
+  TL_HIP(hipMemcpyAsync(m->chain.tasks, host.data(), host.size(), hipMemcpyHostToDevice, m->stream));
+  TL_HIP(hipMemsetAsync(m->chain.sync, 0, sync_bytes, m->stream));
+  TL_HIP(hipStreamSynchronize(m->stream));  // host is a local buffer
+  m->chain.on = true;
+  return 0;
+}
+static int enqueue_sample(tl_model* m, hipStream_t s);
+static int enqueue_sample_topk(tl_model* m, hipStream_t s);
+static int enqueue_step_chain(tl_model* m, bool sampled) {
+  hipStream_t s = m->stream;
+  const int L = m->cfg.num_hidden_layers;
+  TL_TRY(enqueue_embed(m, s));
+  TL_TRY(launch_proj(m, args_qkv(m, 0), s));
+  for (int l = 0; l < L; ++l) {
+    TL_TRY(enqueue_attention(m, l, s, nullptr));
+    const tl_model::Chain::Launch& cl = m->chain.launches[l];
+    TL_TRY(tl_launch_chain(static_cast<const unsigned char*>(m->chain.tasks) + (size_t)cl.first_task * TL_CHAIN_TASK_BYTES,
+                           cl.ntasks, cl.max_nwg, cl.lds, m->chain.counters(cl.first_task), m->chain.gen(), m->chain.err(), s));
+  }
+  if (sampled) TL_TRY(enqueue_sample_topk(m, s));
+  else TL_TRY(enqueue_sample(m, s));
+  return tl_launch_chain_gen_bump(m->chain.gen(), s);
+}
+// after a synchronised run: did a task of a chain launch give up waiting for its predecessor?
+static int chain_check(tl_model* m) {
+  if (!m->chain.on) return 0;
+  unsigned flag = 0;
+  TL_HIP(hipMemcpy(&flag, m->chain.err(), sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag != 0) {
+    TL_HIP(hipMemset(m->chain.err(), 0, sizeof(flag)));
+    tl_set_error("tl_model: a task of a chain launch timed out waiting for its predecessor");
+    return 6;
+  }
+  return 0;
+}
+
 static int enqueue_step(tl_model* m, StepProf* prof = nullptr, bool sampled = false) {
   hipStream_t s = m->stream;
+  if (m->chain.on && !prof) return enqueue_step_chain(m, sampled);
   PROF_MARK(-1);
   TL_TRY(enqueue_embed(m, s));
   PROF_MARK(0);
@@ -902,9 +993,11 @@ extern "C" int tl_model_finalize(tl_model* m) {
   // (TL_TP_PEER_TIMEOUT_MS, 5 s by default) of the others; put a host barrier before it (bench.py does). A rank that
   // waited in vain gets error 5 here and the group is out of step for good: free the models of all ranks.
   if (m->peer_on) TL_TRY(tl_peer_clear_error(m->peer, m->stream));
+  TL_TRY(plan_chain(m));
   TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));
   TL_TRY(enqueue_step(m));
   TL_HIP(hipStreamSynchronize(m->stream));
+  TL_TRY(chain_check(m));
   if (tp_check_peer(m) != 0) {
     tl_set_error("tl_model_finalize: the warm-up step's peer-to-peer exchange timed out: the ranks of a tensor-parallel "
                  "group must call tl_model_finalize together (host barrier first); free this group's models");
@@ -953,6 +1046,7 @@ extern "C" int tl_model_decode(tl_model* m, int token_id, int pos, float* logits
     TL_HIP(hipMemcpyAsync(logits_host, m->logits, sizeof(float) * (size_t)m->cfg.vocab_size, hipMemcpyDeviceToHost, m->stream));
   if (next_token_host) TL_HIP(hipMemcpyAsync(next_token_host, m->state, sizeof(int), hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
+  TL_TRY(chain_check(m));
   return tp_check_peer(m);
 }
 
@@ -976,6 +1070,7 @@ extern "C" int tl_model_generate_greedy(tl_model* m, int first_token, int start_
     TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
                           hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
+  TL_TRY(chain_check(m));
   return tp_check_peer(m);
 }
 
@@ -1028,6 +1123,7 @@ extern "C" int tl_model_generate_sampled(tl_model* m, int first_token, int start
     TL_HIP(hipMemcpyAsync(out_ids_host, m->state + kStateHeaderInts + keep, sizeof(int) * (size_t)n_steps,
                           hipMemcpyDeviceToHost, m->stream));
   TL_HIP(hipStreamSynchronize(m->stream));
+  TL_TRY(chain_check(m));
   return tp_check_peer(m);
 }
 

@@ -312,10 +312,13 @@ def test_model_kv_cache_and_prefill_vs_oracle(E, pkg, oracle):
     om.close()
 
 
-def test_model_tinyllama_shape_two_layers(E, pkg, oracle):
-    """Real TinyLlama-1.1B H/I/heads at 2 layers and a cut vocabulary: logits + greedy stream."""
+@pytest.mark.parametrize("mix", ["q4_k_m", "q8_0"])
+def test_model_tinyllama_shape_two_layers(E, pkg, oracle, mix):
+    """Real TinyLlama-1.1B H/I/heads at 2 layers and a cut vocabulary: logits + greedy stream. q8_0 is
+    BASELINE.json's configs[0] (TinyLlama-1.1B-Chat Q8_0: every matrix dequantize_q8_0_block's format,
+    quantization.cpp:1047-1052), q4_k_m its configs[1]."""
     cfg = dict(pkg.synth.SHAPES["tinyllama-1.1b"], n_layers=2, vocab=2048, max_pos=64)
-    cfg, tensors = pkg.synth.build_model(cfg, "q4_k_m", seed=11)
+    cfg, tensors = pkg.synth.build_model(cfg, mix, seed=11)
     m = E.Model(cfg).load(tensors)
     om = OracleModel(oracle, cfg, tensors)
     prompt = np.array([5, 1900, 77, 1024], np.int32)
@@ -327,6 +330,48 @@ def test_model_tinyllama_shape_two_layers(E, pkg, oracle):
     assert close(logits, want_logits[0], LOGIT_TOL).all(), np.abs(logits - want_logits[0]).max()
     m.free()
     om.close()
+
+
+def test_model_tinyllama_q8_0_prefill_then_decode(E, pkg, oracle):
+    """configs[0] through the generate loop's other branch (api.cpp:601-694): a 40-token prompt goes through the batched
+    prefill, then greedy decode with the default penalty 1.3; ids and the first sampled position's logits vs the oracle."""
+    cfg = dict(pkg.synth.SHAPES["tinyllama-1.1b"], n_layers=2, vocab=2048, max_pos=128)
+    cfg, tensors = pkg.synth.build_model(cfg, "q8_0", seed=12)
+    m = E.Model(cfg).load(tensors)
+    om = OracleModel(oracle, cfg, tensors)
+    prompt = np.random.default_rng(3).integers(0, cfg["vocab"], 40).astype(np.int32)
+    want_ids, want_logits = om.generate(prompt, 8, penalty=1.3, dump_logits=True)
+    assert np.array_equal(m.generate(prompt, 8, penalty=1.3), want_ids)
+    m.reset_kv()
+    last = m.prefill(prompt, 0)
+    assert close(last, want_logits[0], LOGIT_TOL).all(), np.abs(last - want_logits[0]).max()
+    m.free()
+    om.close()
+
+
+@pytest.mark.parametrize("shape,mix", [("tiny", "q4_k_m"), ("tiny", "q8_0"), ("llama-3-8b", "q4_k_m")])
+def test_chain_launches_bit_identical(E, pkg, monkeypatch, shape, mix):
+    """TL_CHAIN=1 (opt-in; a measured negative result): the step's GEMVs between two attention launches as tasks
+    of one persistent launch, handed over through arrival counters: same greedy ids and logits within the decode tolerance of
+    the launch-per-projection step's (and no hand-off may time out)."""
+    if shape == "tiny":
+        cfg, tensors = pkg.synth.build_model("tiny", mix, seed=42)
+    else:
+        cfg = dict(pkg.synth.SHAPES[shape], n_layers=2, vocab=4096, max_pos=64)
+        cfg, tensors = pkg.synth.build_model(cfg, mix, seed=21)
+    out = {}
+    for chain in ("0", "1"):
+        monkeypatch.setenv("TL_CHAIN", chain)
+        m = E.Model(cfg).load(tensors)
+        ids = m.generate(np.array([3, 14, 15, 9], np.int32), 12, penalty=1.3)
+        m.reset_kv()
+        logits = [m.decode(t, p)[0].copy() for p, t in enumerate([7, 1, 22, 5, 9])]
+        out[chain] = (ids, np.stack(logits))
+        m.free()
+    assert np.array_equal(out["0"][0], out["1"][0])
+    # (not bit for bit: every task runs 16 waves, a launch of its own may run 8 or 12, and the RMSNorm's sum of squares is
+    #  formed per thread, then per wave: another association of the same addends)
+    assert close(out["1"][1], out["0"][1], LOGIT_TOL).all(), np.abs(out["1"][1] - out["0"][1]).max()
 
 
 @pytest.mark.parametrize("mix", ["q6_k", "q4_k_m"])

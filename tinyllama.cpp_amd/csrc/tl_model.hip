@@ -124,8 +124,8 @@ struct tl_model {
   } bt;
   // Chain launches (tl_gemv.hip): the step's GEMVs between two attention launches -- attn_output, gate/up, ffn_down and the
   // next layer's QKV (the lm_head after the last layer) -- run as tasks of ONE launch, handed over through arrival counters
-  // instead of kernel boundaries. Planned by tl_model_finalize for unsharded models whose launches all have a chain body;
-  // TL_CHAIN=0 keeps one launch per projection.
+  // instead of kernel boundaries. Planned by tl_model_finalize, when TL_CHAIN=1 is set, for unsharded models whose launches
+  // all have a chain body (a measured negative result: off by default).
   struct Chain {
     bool on = false;
     void* tasks = nullptr;     // device: the tasks of all chain launches, TL_CHAIN_TASK_BYTES each
@@ -685,8 +685,9 @@ static int enqueue_sample_topk(tl_model* m, hipStream_t s) {
 // attn_output -> gate/up -> ffn_down -> next QKV (lm_head after the last layer) | sampling | generation bump.
 static int plan_chain(tl_model* m) {
   m->chain.on = false;
-  if (const char* e = getenv("TL_CHAIN"))
-    if (atoi(e) == 0) return 0;
+  // opt-in: measured SLOWER than one launch per projection in both forms built (profiles/r03_a_chain_*)
+  const char* e = getenv("TL_CHAIN");
+  if (!e || atoi(e) == 0) return 0;
   if (m->tp != 1 || m->comm || m->has_f32 || !m->attn_split) return 0;
   const int L = m->cfg.num_hidden_layers;
   std::vector<unsigned char> host((size_t)L * 4 * TL_CHAIN_TASK_BYTES, 0);

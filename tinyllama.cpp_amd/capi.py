@@ -77,12 +77,6 @@ SIGNATURES = {
                                   C.c_uint64, _vp],
     "tl_sample_top_k_top_p": [_vp, C.c_int, C.c_float, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp],
     "tl_gemm_set_terms": [C.c_int],
-    "tl_bench_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), _vp],
-    "tl_bench_matvec_prefetch": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float)],
-    "tl_stream_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.POINTER(C.c_float), _vp],
-    "tl_debug_gemv_stamps": [_vp, _fp, _fp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp],
-    "tl_model_profile_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
-    "tl_model_bench_kernel": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)],
     "tl_model_device_ptr": [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "tl_model_bytes_per_token": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
     "tl_tp_unique_id": [_vp],
@@ -105,10 +99,22 @@ SIGNATURES = {
 
 # include/tlhip_debug.h: measurement / diagnostic hooks (not part of the boundary)
 DEBUG_SIGNATURES = {
+    "tl_bench_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float), _vp],
+    "tl_bench_matvec_prefetch": [_vp, C.c_int, _fp, _fp, C.c_int, C.c_int, C.POINTER(C.c_float)],
+    "tl_debug_gemv_stamps": [_vp, _fp, _fp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int), _vp],
+    "tl_model_profile_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
+    "tl_model_bench_kernel": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)],
     "tl_chain_set_stamps": [_vp, _sz],
 }
 
+# libtlhip_tools.so (csrc/tl_stream.hip): experiments kept out of the product library; declared in include/tlhip_debug.h
+TOOLS_LIB_PATH = os.path.join(HERE, "csrc", "libtlhip_tools.so")
+TOOLS_SIGNATURES = {
+    "tl_stream_matvec": [_vp, C.c_int, _fp, _fp, C.c_int, C.POINTER(C.c_float), _vp],
+}
+
 _lib = None
+_tools_lib = None
 
 
 def lib():
@@ -127,6 +133,22 @@ def lib():
             fn.argtypes = argtypes
         _lib = L
     return _lib
+
+
+def tools_lib():
+    """libtlhip_tools.so with typed entry points (it links against libtlhip.so, which is loaded first)."""
+    global _tools_lib
+    if _tools_lib is None:
+        lib()
+        if not os.path.exists(TOOLS_LIB_PATH):
+            raise TlError(f"{TOOLS_LIB_PATH} is missing: build it with `make -C tinyllama.cpp_amd/csrc`")
+        L = C.CDLL(TOOLS_LIB_PATH)
+        for name, argtypes in TOOLS_SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = C.c_int
+            fn.argtypes = argtypes
+        _tools_lib = L
+    return _tools_lib
 
 
 def check(rc, what=""):

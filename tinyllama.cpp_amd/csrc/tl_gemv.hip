@@ -28,7 +28,6 @@
 #include <vector>
 
 #include "tl_internal.h"
-#include "tlhip_debug.h"
 
 #include "tl_chunk.h"
 

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "tlhip.h"
+#include "tlhip_debug.h"
 
 // ---- error plumbing -------------------------------------------------------------------------------
 void tl_set_error(const char* fmt, ...);

@@ -15,7 +15,7 @@ from _pkg import load_package  # noqa: E402
 pkg = load_package()
 S = pkg.synth
 from tinyllama_cpp_amd import engine  # noqa: E402
-from tinyllama_cpp_amd.capi import check, lib  # noqa: E402
+from tinyllama_cpp_amd.capi import check, lib, tools_lib  # noqa: E402
 
 TYPES = {"q4_k": S.Q4_K, "q6_k": S.Q6_K, "q8_0": S.Q8_0}
 
@@ -33,7 +33,7 @@ def run(typ_name, rows, cols, timed, out):
     check(lib().tl_memset(ys.ptr, 0xff, ys.nbytes, None))
     arr = (C.c_void_p * nw)(*[w.h for w in ws])
     us_s, us_l = C.c_float(), C.c_float()
-    rc = lib().tl_stream_matvec(arr, nw, x.ptr, ys.ptr, 20 if timed else 1, C.byref(us_s), None)
+    rc = tools_lib().tl_stream_matvec(arr, nw, x.ptr, ys.ptr, 20 if timed else 1, C.byref(us_s), None)
     if rc == 2 and b"stream:" in lib().tl_last_error():  # a shape the engine's item geometry does not cover
         print(json.dumps({"type": typ_name, "rows": rows, "cols": cols, "unsupported": lib().tl_last_error().decode()}), flush=True)
         return True

@@ -300,10 +300,20 @@ def main():
     # whole eager steps with an event after every launch (includes ~5 us of event overhead per launch; the GEMV rows
     # above are the clean numbers): kept for the non-GEMV kernels
     prof = model.profile_decode(int(ids[-1]), pos + args.steps, min(8, max(1, cfg["max_pos"] - pos - args.steps)))
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_zz_gate_up_traffic.json")
-    if args.workload == "llama-3-8b" and world == 1 and os.path.exists(tpath):  # PMC pass of this kernel on this workload (profiles/)
-        traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+    # roofline.traffic is a KEPT figure: the --pmc FETCH_SIZE pass of this kernel on this workload (tools/gpu/r03_prof_round.sh
+    # -> profiles/latest_gate_up_traffic.json), not measured in this process. The file carries a hash of the GEMV sources
+    # it was measured on; a figure of other sources is not reported (traffic = null, the reason in traffic_source).
+    traffic, traffic_source, rocprof_us = None, "no kept PMC figure for this workload", None
+    tpath = os.path.join(ROOT, "profiles", "latest_gate_up_traffic.json")
+    if args.workload == "llama-3-8b" and mix == "q4_k_m" and world == 1 and os.path.exists(tpath):
+        kept = json.load(open(tpath))
+        if kept.get("gemv_sources_sha256") == gemv_sources_hash():
+            traffic = kept.get("hbm_bytes_per_launch")
+            rocprof_us = kept.get("rocprof_avg_launch_us")
+            traffic_source = ("kept PMC figure, not measured in this process: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) on these "
+                              "GEMV sources, profiles/latest_gate_up_traffic.json")
+        else:
+            traffic_source = "stale: profiles/latest_gate_up_traffic.json was measured on other GEMV sources (hash differs)"
 
     out = {
         "metric": METRIC,
@@ -333,8 +343,14 @@ def main():
         "hbm_frac_whole_step": round((w_bytes + kv_bytes) / (dt / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
         "roofline": {"bound": "hbm", "kernel": "gemv_kernel<.., GEMV_GATE_UP> (RMSNorm + ffn_gate/ffn_up GEMV + SwiGLU)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "bytes_per_launch": int(gu_bytes), "avg_launch_us": round(gu_us, 2),
+                     "timed_with": "HIP events on the engine's stream around back-to-back launches (achieved and frac are from these)",
+                     # the same kernel's average duration in the kept rocprofv3 --kernel-trace --stats summary, and the
+                     # fraction it gives (the profiler's per-dispatch time excludes the boundary the event pair includes
+                     # and adds its own overhead: the two differ by a few percent)
+                     "rocprof_avg_launch_us": rocprof_us,
+                     "frac_rocprof": round(gu_bytes / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4) if rocprof_us else None,
                      "launches": 8 * cfg["n_layers"]},
         "gemv_kernels": kern,
         "eager_step_us": {k: round(v[0] * 1e3, 2) for k, v in prof.items()},
@@ -382,6 +398,15 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def gemv_sources_hash():
+    """sha256 over the sources of the decode GEMV kernels (what a kept PMC figure was measured on)"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("tl_gemv.hip", "tl_chunk.h", "tl_internal.h"):
+        h.update(open(os.path.join(ROOT, "tinyllama.cpp_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def batch_leg(model, cfg, B, plen=16, steps=16, terms=6):

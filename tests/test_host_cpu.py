@@ -79,6 +79,28 @@ def test_gguf_reader_rejects_malformed_files(H, pkg, tmp_path):
     g.close()
 
 
+def test_llama3_file_without_rope_base_gets_500000(H, pkg, tmp_path):
+    """model_config.cpp:242-248: a file classified LLAMA3_TIKTOKEN (gpt2 + merges + 128256 vocabulary entries) that lacks
+    llama.rope.freq_base runs with rope_theta 500000, not the 10000 default; an explicit 10000 stays; other families keep
+    the default."""
+    S = pkg.synth
+    toks = [b"a", b"b", b"ab"]
+
+    def theta(kvs, **kw):
+        g = H.GGUF(S.write_metadata_gguf(str(tmp_path / f"r{len(list(tmp_path.iterdir()))}.gguf"), kvs, **kw))
+        t = g.model_config()["rope_theta"]
+        g.close()
+        return t
+
+    l3 = S.tokenizer_kvs(toks, model="gpt2", merges=[b"a b"], vocab_size=128256)
+    assert theta(l3) == 500000.0
+    assert theta(l3 + [S._kv_f32("llama.rope.freq_base", 10000.0)]) == 10000.0
+    assert theta(l3 + [S._kv_f32("llama.rope.freq_base", 250000.0)]) == 250000.0
+    assert theta(S.tokenizer_kvs(toks, model="llama", scores=[0.0, -1.0, -2.0])) == 10000.0
+    # gpt2 + merges with an ordinary vocabulary size is NOT Llama-3 (model_config.cpp:232)
+    assert theta(S.tokenizer_kvs(toks, model="gpt2", merges=[b"a b"], vocab_size=32000)) == 10000.0
+
+
 def test_gguf_reader_matches_the_reference_parser(H, golden, tmp_path):
     """tests/golden/g4_gguf.npz holds a synthetic GGUF file (every scalar metadata type, tokenizer arrays, alignment 64)
     and what the REFERENCE'S OWN load_gguf_meta (gguf_parser.cpp:123) parsed from it (oracle/make_golden.py g4):

@@ -74,6 +74,12 @@ ModelConfig config_from_gguf(const GGUFFile& f) {
   if (c.max_position_embeddings <= 0 || c.max_position_embeddings > 8192) c.max_position_embeddings = 2048;
   c.rms_norm_eps = meta_float(f, "llama.attention.layer_norm_rms_epsilon", 1e-5f);
   c.rope_theta = meta_float(f, "llama.rope.freq_base", 10000.0f);
+  // model_config.cpp:242-248: a file classified LLAMA3_TIKTOKEN whose rope_theta came out as 10000 re-reads the key with a
+  // default of 500000 and takes it when it is above 10000 -- i.e. a Llama-3 file WITHOUT llama.rope.freq_base runs at 500000
+  if (c.rope_theta == 10000.0f && tokenizer_family_from_gguf(f) == TokenizerFamily::LLAMA3_TIKTOKEN) {
+    const float cand = meta_float(f, "llama.rope.freq_base", 500000.0f);
+    if (cand > 10000.0f) c.rope_theta = cand;
+  }
   c.bos_token_id = meta_int(f, "tokenizer.ggml.bos_token_id", -1);  // (-1: no such token, model_config.cpp:199-200)
   c.eos_token_id = meta_int(f, "tokenizer.ggml.eos_token_id", -1);
   c.architecture = meta_str(f, "general.architecture");

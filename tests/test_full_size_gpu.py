@@ -121,3 +121,65 @@ def test_multi_sequence_decode_agrees_with_single_sequence_at_full_size(big):
             lg, ids = single[i]
             assert close(logits[j], lg, TOL).all(), (len(members), i, np.abs(logits[j] - lg).max())
             assert np.array_equal(np.concatenate([[first[j]], more[:, j]]), ids), (len(members), i)
+
+
+# ---- BASELINE.json configs[4]: the Llama-3-70B-shaped model on ONE GPU (the N = 1 anchor of its tensor-parallel curve) ----
+@pytest.fixture(scope="module")
+def big70(pkg):
+    """The 70B layer shape (H 8192, I 28672, 64 / 8 heads of 128) and its full vocabulary at 4 layers: every launch has
+    its full-size geometry (8192- and 28672-column x images, four / fourteen spans per row, 64 query heads over 8 kv
+    heads); the depth is cut so that the synthetic weights (3.6 GB instead of 41 GB) are made in seconds."""
+    from tinyllama_cpp_amd import engine as E
+    E.init(0)
+    S = pkg.synth
+    cfg = dict(S.SHAPES["llama-3-70b"], n_layers=4, max_pos=256)
+    m = E.Model(cfg)
+    for name, typ, rows, cols in S.tensor_plan(cfg, "q4_k_m"):
+        m.set_tensor(name, typ, S.make_tensor(name, typ, rows, cols, seed=42), rows, cols)
+    m.finalize()
+    yield E, cfg, m
+    m.free()
+
+
+def test_70b_shape_prefill_and_decode_paths_agree(big70):
+    E, cfg, m = big70
+    toks = np.random.default_rng(1).integers(0, cfg["vocab"], 72).astype(np.int32)
+    m.reset_kv()
+    for pos, t in enumerate(toks):
+        serial, _ = m.decode(int(t), pos, want_logits=(pos == len(toks) - 1))
+    k_serial = [m.kv_cache(l, len(toks)) for l in (0, 3)]
+    cont_serial = m.generate_greedy(int(np.argmax(serial)), len(toks), 10, 1.3, history=[int(np.argmax(serial))])
+    m.reset_kv()
+    batched = m.prefill(toks, 0)
+    assert np.isfinite(batched).all()
+    assert close(batched, serial, TOL).all(), np.abs(batched - serial).max()
+    for (ks, vs), l in zip(k_serial, (0, 3)):
+        kb, vb = m.kv_cache(l, len(toks))
+        assert (np.abs(kb - ks) <= KV_TOL * np.maximum(1.0, np.abs(ks))).all(), l
+        assert (np.abs(vb - vs) <= KV_TOL * np.maximum(1.0, np.abs(vs))).all(), l
+    cont_batched = m.generate_greedy(int(np.argmax(batched)), len(toks), 10, 1.3, history=[int(np.argmax(batched))])
+    assert np.array_equal(cont_batched, cont_serial)
+    # deterministic: the same stream twice
+    m.reset_kv()
+    a = m.generate_greedy(23, 0, 16, 1.3)
+    m.reset_kv()
+    assert np.array_equal(a, m.generate_greedy(23, 0, 16, 1.3))
+
+
+def test_70b_shape_rows_against_oracle(big70, pkg, oracle):
+    """Rows sampled from the 70B-shaped matrices (28672 x 8192, 8192 x 28672, the kv projections) against the oracle."""
+    E, cfg, m = big70
+    S = pkg.synth
+    rng = np.random.default_rng(4)
+    plan = {name: (typ, rows, cols) for name, typ, rows, cols in S.tensor_plan(cfg, "q4_k_m")}
+    picks = ("blk.0.ffn_gate.weight", "blk.0.ffn_down.weight", "blk.2.ffn_down.weight", "blk.2.attn_v.weight")
+    assert [plan[n][0] for n in picks] == [S.Q4_K, S.Q4_K, S.Q6_K, S.Q6_K]
+    for name, typ, rows, cols in ((n,) + plan[n] for n in picks):
+        blocks = S.make_tensor(name, typ, rows, cols, seed=42)
+        x = rng.standard_normal(cols).astype(np.float32)
+        y = E.QWeight(typ, blocks, rows, cols).matvec(x)
+        pick = np.sort(rng.choice(rows, 48, replace=False))
+        per_row = cols // S.BLOCK_ELEMS[typ]
+        sub = blocks.reshape(rows, per_row, -1)[pick].reshape(48 * per_row, -1)
+        want = oracle.matvec_q(typ, sub, x, 48, cols)
+        assert close(y[pick], want, TOL).all(), name

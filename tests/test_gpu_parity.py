@@ -374,6 +374,41 @@ def test_chain_launches_bit_identical(E, pkg, monkeypatch, shape, mix):
     assert close(out["1"][1], out["0"][1], LOGIT_TOL).all(), np.abs(out["1"][1] - out["0"][1]).max()
 
 
+@pytest.mark.parametrize("shape,mix,start", [("tiny-gqa", "q4_k_m", 0), ("tiny-gqa", "q8_0", 70), ("tinyllama-1.1b", "q8_0", 130),
+                                             ("llama-3.2-3b", "q6_k", 200), ("llama-3-8b", "q4_k_m", 0),
+                                             ("llama-3-8b", "q4_k_m", 1000), ("llama-3-8b", "q4_k_m", 1100)])
+def test_attention_folded_into_attn_output_launch(E, pkg, monkeypatch, shape, mix, start):
+    """TL_FUSED_ATTN=1: every layer's RoPE + KV write + split attention runs inside the layer's attn_output launch (four
+    dependent launches per layer instead of five; the partial records are handed over inside the launch). Same greedy ids,
+    logits within the decode tolerance and the same K/V rows as the step with an attention launch of its own, from an empty
+    cache and over seeded caches up to and across 1024 positions (16 splits, the most this form is meant for)."""
+    if shape == "tiny-gqa":
+        cfg = dict(pkg.synth.SHAPES[shape])
+    else:
+        cfg = dict(pkg.synth.SHAPES[shape], n_layers=2, vocab=4096, max_pos=1280)
+    cfg, tensors = pkg.synth.build_model(cfg, mix, seed=23)
+    kvd = cfg["n_kv_heads"] * (cfg["hidden"] // cfg["n_heads"])
+    out = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("TL_FUSED_ATTN", fused)
+        m = E.Model(cfg).load(tensors)
+        rng = np.random.default_rng(start)
+        for layer in range(cfg["n_layers"] if start else 0):
+            m.set_kv_cache(layer, (rng.standard_normal((start, kvd)) * 0.7).astype(np.float32),
+                           rng.standard_normal((start, kvd)).astype(np.float32))
+        logits = [m.decode(t, start + p)[0].copy() for p, t in enumerate([7, 1, 22, 5, 9])]
+        ids = m.generate_greedy(3, start + 5, 12, 1.3)
+        kv = [m.kv_cache(layer, start + 17) for layer in range(cfg["n_layers"])]
+        out[fused] = (ids, np.stack(logits), kv, m.graph_nodes())
+        m.free()
+    L = cfg["n_layers"]
+    assert out["0"][3] == 5 * L + 4 and out["1"][3] == 4 * L + 5, (out["0"][3], out["1"][3])  # the folded form really ran
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert close(out["1"][1], out["0"][1], LOGIT_TOL).all(), np.abs(out["1"][1] - out["0"][1]).max()
+    for (k0, v0), (k1, v1) in zip(out["0"][2], out["1"][2]):
+        assert close(k1[start:], k0[start:], LOGIT_TOL).all() and close(v1[start:], v0[start:], LOGIT_TOL).all()
+
+
 @pytest.mark.parametrize("mix", ["q6_k", "q4_k_m"])
 def test_model_llama32_3b_shape_two_layers(E, pkg, oracle, mix):
     """Llama-3.2-3B's hidden size 3072 = 96 chunks per row: the projections that read the hidden vector run the

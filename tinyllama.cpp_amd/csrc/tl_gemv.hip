@@ -30,6 +30,7 @@
 #include "tl_internal.h"
 
 #include "tl_chunk.h"
+#include "tl_attn_body.h"
 
 // the vector-side arguments of a launch (the segments travel as separate kernel parameters)
 struct GemvVec {
@@ -68,6 +69,7 @@ struct GemvVec {
 constexpr int CHAIN_SHARDS = 8;
 constexpr int CHAIN_SHARD_WORDS = 32;                                // 128 B apart
 constexpr int CHAIN_TASK_WORDS = CHAIN_SHARDS * CHAIN_SHARD_WORDS;  // counter words per task
+constexpr unsigned long long CHAIN_TIMEOUT_TICKS = 200000000ull;    // 2 s of the 100 MHz realtime counter
 struct ChainWait {
   const unsigned* cnt;  // the predecessor task's arrival counters (CHAIN_SHARDS shards); nullptr: nothing to wait for
   unsigned gen1;        // generation + 1
@@ -77,11 +79,76 @@ struct ChainWait {
   // [0] entry, [1] first weight loads issued, [2] predecessor seen, [3] x staged, [4] last loads issued, [5] all stores
   // acknowledged and the workgroup met, [6] arrival added
   unsigned long long* st;
+  // != nullptr: this launch carries its layer's attention (gemv_attn_kernel below): the wait is for that, not for a task
+  const struct FusedAttn* fa;
+  float* attn_smem;  // LDS of the attention body (behind the x image)
+  int bid, grid;
+};
+// The attention of a layer folded into the layer's attn_output launch. Workgroup b < n_kv_heads x zparts x active splits
+// runs the split-attention body for (split b / (nkv zparts), kv head, part) while every wave's first weight loads are
+// already in flight, stores its partial records written-through and arrives at `count`; the last arrival resets the
+// counter and publishes the launch's epoch (CHAIN_SHARDS copies on lines of their own), which wave 0 of EVERY workgroup
+// polls for before the x staging combines the records (sc1 loads). epoch = generation x layers + layer + 1: a value no
+// earlier launch has published, so nothing needs clearing; the generation word is advanced once per step by a kernel of
+// its own. All workgroups of the launch are resident (one per CU), so every poller's producer is running or done.
+struct FusedAttn {
+  AttnArgs at;
+  unsigned* count;
+  unsigned* epoch;
+  const unsigned* gen;
+  unsigned tag, tags_per_gen;
+  unsigned* err;
+  // diagnostic run only (tl_chain_set_stamps): 8 realtime stamps per workgroup, written by thread 0: [0] entry, [1] first
+  // weight loads issued, [2] all attention records published, [3] x staged, [4] last loads issued, [7] thread 0 done; for
+  // the workgroups with an attention task: [5] its records acknowledged, [6] its arrival added
+  unsigned long long* st;
 };
 __device__ __forceinline__ void chain_stamp(const ChainWait* cw, int k) {
   if (cw->st != nullptr && threadIdx.x == 0) cw->st[k] = __builtin_amdgcn_s_memrealtime();
 }
-constexpr unsigned long long CHAIN_TIMEOUT_TICKS = 200000000ull;  // 2 s of the 100 MHz realtime counter
+template <int HD, int G>
+__device__ __forceinline__ void fused_attention_phase(const ChainWait& cw, int wave, int lane) {
+  const FusedAttn& f = *cw.fa;
+  const int pos = *f.at.pos_dev;  // (uniform: a scalar load)
+  const int len = pos + 1;
+  const int SL = tl_attn_split_len(len), active = (len + SL - 1) / SL;
+  const int per = f.at.nkv * f.at.zparts;
+  const int ntasks = (pos >= 0 && pos < f.at.max_seq) ? per * active : 0;
+  if (ntasks == 0) return;  // (the position is out of range: the step's other kernels ignore it too)
+  for (int t = cw.bid; t < ntasks; t += cw.grid) {
+    const int split = t / per, r = t - split * per, z = r / f.at.nkv, kvh = r - z * f.at.nkv;
+    tl_attn::attn_split_body<HD, G, true, 2, true>(f.at, kvh, split, z, cw.attn_smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's record stores have been acknowledged
+    __syncthreads();                                  // ... every wave's; the body's LDS is free again
+  }
+  const unsigned target = *f.gen * f.tags_per_gen + f.tag;
+  if (cw.bid < ntasks) chain_stamp(&cw, 5);
+  if (cw.bid < ntasks && threadIdx.x == 0) {
+    const unsigned arrivals = (unsigned)(ntasks < cw.grid ? ntasks : cw.grid);
+    const unsigned before = __hip_atomic_fetch_add(f.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (before + 1u == arrivals) {
+      __hip_atomic_store(f.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int c = 0; c < CHAIN_SHARDS; ++c)
+        __hip_atomic_store(f.epoch + c * CHAIN_SHARD_WORDS, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (cw.st != nullptr) cw.st[6] = __builtin_amdgcn_s_memrealtime();
+  }
+  if (wave == 0) {
+    const unsigned* p = f.epoch + (cw.bid & (CHAIN_SHARDS - 1)) * CHAIN_SHARD_WORDS;
+    const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + CHAIN_TIMEOUT_TICKS;
+    for (unsigned it = 1;; ++it) {
+      const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__builtin_amdgcn_readfirstlane(v) == target) break;
+      if ((it & 255u) == 0u && __builtin_amdgcn_s_memrealtime() > deadline) {
+        if (lane == 0) atomicOr(f.err, 1u);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
 
 __device__ __forceinline__ void chain_wait(const ChainWait& cw, int wave, int lane) {
   if (cw.cnt == nullptr) return;  // (uniform)
@@ -138,6 +205,7 @@ struct XRegs {
 
 constexpr int XA_CHUNK = 6;
 // issue the loads of splits [s0, s0 + XA_CHUNK) (clamped to the active ones) of float4 index i
+template <bool CHAIN = false>
 __device__ __forceinline__ void xattn_issue(const GemvVec& a, int i, int s0, int active, f32x4* ao, float* am, float* al) {
   const int hd = a.attn_hd, recl = hd + 4;
   const int e = i << 2, h = e / hd, d = e - h * hd;
@@ -146,9 +214,16 @@ __device__ __forceinline__ void xattn_issue(const GemvVec& a, int i, int s0, int
   for (int k = 0; k < XA_CHUNK; ++k) {
     const int s = s0 + k < active ? s0 + k : active - 1;  // unconditional loads (counted waits), clamped
     const float* rec = rec0 + (size_t)s * recl;
-    ao[k] = *reinterpret_cast<const f32x4*>(rec + d);
-    am[k] = rec[hd];
-    al[k] = rec[hd + 1];
+    if constexpr (CHAIN) {  // the records may have been written in THIS launch (attention folded in): sc1 loads
+      const unsigned ro = (unsigned)((h * TL_ATTN_MAX_SPLITS + s) * recl);  // (wave-uniform base, per-lane offset)
+      ao[k] = ldx4<true>(a.attn_ws, (ro + (unsigned)d) * 4u);
+      am[k] = ldx1<true>(a.attn_ws + ro + hd);
+      al[k] = ldx1<true>(a.attn_ws + ro + hd + 1);
+    } else {
+      ao[k] = *reinterpret_cast<const f32x4*>(rec + d);
+      am[k] = rec[hd];
+      al[k] = rec[hd + 1];
+    }
   }
 }
 // fold a chunk into the running (M, L, O) of a float4
@@ -179,7 +254,7 @@ __device__ __forceinline__ void stage_x_issue(const GemvVec& a, XRegs& r) {
     asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pos) : "s"(a.attn_pos) : "memory");
     r.active = tl_attn_records(pos + 1, a.attn_merged != 0);
     const int i = threadIdx.x < (unsigned)n4 ? threadIdx.x : n4 - 1;
-    xattn_issue(a, i, 0, r.active, r.ao, r.am, r.al);
+    xattn_issue<CHAIN>(a, i, 0, r.active, r.ao, r.am, r.al);
     return;
   }
   const void* wbase = a.norm_w ? a.norm_w : a.x;
@@ -210,13 +285,13 @@ __device__ __forceinline__ void stage_x_finish(const GemvVec& a, const XRegs& r,
       } else {
         f32x4 ao[XA_CHUNK];
         float am[XA_CHUNK], al[XA_CHUNK];
-        xattn_issue(a, i, 0, r.active, ao, am, al);
+        xattn_issue<CHAIN>(a, i, 0, r.active, ao, am, al);
         xattn_fold(0, r.active, ao, am, al, M, L, O);
       }
       for (int s0 = XA_CHUNK; s0 < r.active; s0 += XA_CHUNK) {
         f32x4 ao[XA_CHUNK];
         float am[XA_CHUNK], al[XA_CHUNK];
-        xattn_issue(a, i, s0, r.active, ao, am, al);
+        xattn_issue<CHAIN>(a, i, s0, r.active, ao, am, al);
         xattn_fold(s0, r.active, ao, am, al, M, L, O);
       }
       const float inv = 1.0f / (L + 1e-9f);
@@ -403,7 +478,9 @@ struct StepMeta {
 // loads complete in order, so a load in the epilogue would drain the whole prefetch queue once per row group.
 // CHAIN (a task of a chain launch): x and the first residual values are loaded only AFTER the wait for the predecessor
 // task, which follows the first weight loads; activation loads and stores take their sc1 forms.
-template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP, bool PEER = false, bool CHAIN = false>
+// AHD > 0 (with CHAIN): the launch carries its layer's attention (fused_attention_phase<AHD, AG>) in place of the wait.
+template <int TYPE, bool PAIR, bool RESID, bool XATTN, bool STAMP, bool PEER = false, bool CHAIN = false, int AHD = 0,
+          int AG = 0>
 __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, XRegs& xr, float* smem, int first,
                                           int stride, int total, int lane, unsigned long long* ts, unsigned pe = 0,
                                           int peer_wave = 0, const ChainWait* cw = nullptr) {
@@ -416,7 +493,8 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, XRegs
   if (first >= total) {  // a wave without work only helps staging x
     if (STAMP) ts[3] = __builtin_readcyclecounter();
     if constexpr (CHAIN) {
-      chain_wait(*cw, peer_wave, lane);
+      if constexpr (AHD > 0) fused_attention_phase<AHD, AG>(*cw, peer_wave, lane);
+      else chain_wait(*cw, peer_wave, lane);
       stage_x_issue<XATTN, CHAIN>(a, xr);
     }
     stage_x_finish<XATTN, CHAIN>(a, xr, smem);
@@ -504,7 +582,8 @@ __device__ __forceinline__ void run_class(const Segs& g, const GemvVec& a, XRegs
   if (STAMP) ts[3] = __builtin_readcyclecounter();
   if constexpr (CHAIN) {  // the predecessor task's output exists from here on
     chain_stamp(cw, 1);
-    chain_wait(*cw, peer_wave, lane);
+    if constexpr (AHD > 0) fused_attention_phase<AHD, AG>(*cw, peer_wave, lane);
+    else chain_wait(*cw, peer_wave, lane);
     chain_stamp(cw, 2);
     stage_x_issue<XATTN, CHAIN>(a, xr);
     if (RESID) {
@@ -703,7 +782,8 @@ __device__ __forceinline__ void run_class_flat(const Segs& g, const GemvVec& a, 
 // all-gather otherwise.
 // The body of a launch; `bid` is the workgroup's index among the a.grid workgroups of the launch (blockIdx.x), or of its
 // task in a chain launch (CHAIN; cw says what to wait for; RA = 0, no PEER).
-template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false, bool CHAIN = false>
+template <int TA, int TB, bool PAIR, int ROLE, bool STAMP = false, int RA = 0, bool PEER = false, bool CHAIN = false,
+          int AHD = 0, int AG = 0>
 __device__ __forceinline__ void gemv_body(const GemvSeg& sg0, const GemvSeg& sg1, const GemvSeg& sg2, const GemvVec& a,
                                           int t0, int t1, int t2, int nsegA, int wavesA, int bid, float* smem,
                                           const ChainWait* cw = nullptr) {
@@ -747,8 +827,8 @@ __device__ __forceinline__ void gemv_body(const GemvSeg& sg0, const GemvSeg& sg1
     if constexpr (RA > 0)
       run_class_flat<TA, PAIR, RESID, XATTN, RA>(g, a, xr, smem, wave * a.grid + bid, a.grid * wA, total, lane);
     else
-      run_class<TA, PAIR, RESID, XATTN, STAMP, PEER, CHAIN>(g, a, xr, smem, wave * a.grid + bid, a.grid * wA, total, lane,
-                                                            ts, pe, wave, cw);
+      run_class<TA, PAIR, RESID, XATTN, STAMP, PEER, CHAIN, AHD, AG>(g, a, xr, smem, wave * a.grid + bid, a.grid * wA, total,
+                                                                     lane, ts, pe, wave, cw);
   } else if (TB != TL_NONE) {
     constexpr int TBB = TB == TL_NONE ? TA : TB;
     const GemvSeg sb = nsegA == 1 ? sg1 : sg2;  // wave-uniform, two-way: stays in SGPRs
@@ -794,6 +874,25 @@ __global__ __launch_bounds__(GEMV_MAX_THREADS) void gemv_kernel(GemvSeg sg0, Gem
                                                                 int t0, int t1, int t2, int nsegA, int wavesA, GemvPad) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   gemv_body<TA, TB, PAIR, ROLE, STAMP, RA, PEER>(sg0, sg1, sg2, a, t0, t1, t2, nsegA, wavesA, blockIdx.x, smem);
+}
+
+// ---- the attn_output launch that carries its layer's attention (RoPE + KV write + split attention, tl_attn_body.h) -------
+// 512 threads (the attention body's geometry: 8 waves, up to 256 VGPRs), one workgroup per CU. Every wave first issues the
+// weight loads of its first step, then the workgroups that have an attention task run it, everybody waits for the last of
+// them (fused_attention_phase) and the x staging combines the partial records: the attention's launch boundary, prologue
+// and tail are gone and what is left of its latency overlaps the first HBM round trip of the projection. For sequences of
+// at most FUSED_ATTN_MAX_LEN positions (16 splits of 64: beyond that the consumer's combine of up to 32 records per head
+// costs more than the split kernel's in-kernel merge, and the step keeps its own attention launch).
+template <int TA, int HD, int G>
+__global__ __launch_bounds__(tl_attn::ATT_THREADS) void gemv_attn_kernel(GemvSeg sg0, GemvVec a, int t0, FusedAttn fa) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nchunks = a.cols >> 5;
+  const ChainWait cw = {nullptr, 0u, 0, fa.err, fa.st ? fa.st + 8 * (size_t)blockIdx.x : nullptr, &fa,
+                        smem + XS_SCRATCH + nchunks * XS_STRIDE, (int)blockIdx.x, a.grid};
+  chain_stamp(&cw, 0);
+  gemv_body<TA, TL_NONE, false, GEMV_ATTN_OUT_COMBINE, false, 0, false, true, HD, G>(sg0, sg0, sg0, a, t0, 0, 0, 1, a.nthr >> 6,
+                                                                                        blockIdx.x, smem, &cw);
+  chain_stamp(&cw, 7);
 }
 
 // ---- the chain launch: grid (workgroups per task, tasks); every workgroup runs the body its task names -------------------
@@ -1177,9 +1276,93 @@ int tl_launch_gemv(const GemvArgs& a, hipStream_t s) {
   return 0;
 }
 
-// ---- chain launches: host side -------------------------------------------------------------------------------------------
 static unsigned long long* g_chain_stamps = nullptr;
 static size_t g_chain_stamps_cap = 0, g_chain_stamps_used = 0;
+// ---- the attn_output launch that carries its layer's attention: host side ---------------------------------------------
+static_assert(TL_SYNC_LINE_WORDS == CHAIN_SHARD_WORDS, "one counter per 128-byte line");
+size_t tl_fused_attn_sync_words() { return (size_t)(2 + CHAIN_SHARDS) * CHAIN_SHARD_WORDS; }  // count | generation | epochs
+
+template <int TA, int HD, int G>
+static int gemv_attn_launch(const Launch& L, const FusedAttn& fa, hipStream_t s) {
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemv_attn_kernel<TA, HD, G>, 160 * 1024, lds_raised));
+  GemvVec v = L.v;
+  v.nthr = L.threads;
+  v.grid = L.grid;
+  const size_t lds = L.lds + sizeof(float) * tl_attn::attn_split_lds_floats<HD, G>();
+  TL_REQUIRE(lds <= 160 * 1024, "gemv+attention: %zu B of LDS (> 160 KiB)", lds);
+  gemv_attn_kernel<TA, HD, G><<<L.grid, L.threads, lds, s>>>(L.seg[0], v, L.t[0], fa);
+  return 0;
+}
+template <int TA>
+static int gemv_attn_launch_shape(const Launch& L, const FusedAttn& fa, int G, hipStream_t s) {
+  if (fa.at.hd == 64) return G == 4 ? gemv_attn_launch<TA, 64, 4>(L, fa, s) : gemv_attn_launch<TA, 64, 3>(L, fa, s);
+  return G == 4 ? gemv_attn_launch<TA, 128, 4>(L, fa, s) : gemv_attn_launch<TA, 128, 3>(L, fa, s);
+}
+// query heads per workgroup of the folded attention (tl_attn.hip's rule); 0: no folded form for this head configuration
+static int fused_attn_heads(const AttnArgs& t) {
+  if (!(t.hd == 64 || t.hd == 128) || t.nkv <= 0 || t.nh % t.nkv != 0) return 0;
+  const int group = t.nh / t.nkv;
+  return group % 4 == 0 ? 4 : (group % 3 == 0 ? 3 : 0);
+}
+bool tl_gemv_attn_supported(const GemvArgs& a, const AttnArgs& t) {
+  Launch L;
+  int role = GEMV_GENERIC;
+  bool classB = false, plain = false;
+  if (gemv_plan(a, L, &role, &classB, &plain) != 0) return false;
+  const int ta = a.seg[0].w.type;
+  if (!plain || role != GEMV_ATTN_OUT_COMBINE || L.ra != 0 || a.peer || a.attn_merged) return false;
+  if (!(ta == TL_Q4_K || ta == TL_Q6_K || ta == TL_Q8_0)) return false;
+  const int G = fused_attn_heads(t);
+  if (G == 0 || a.cols != t.nh * t.hd) return false;
+  const size_t att = sizeof(float) * (t.hd == 64 ? (G == 4 ? tl_attn::attn_split_lds_floats<64, 4>() : tl_attn::attn_split_lds_floats<64, 3>())
+                                                 : (G == 4 ? tl_attn::attn_split_lds_floats<128, 4>() : tl_attn::attn_split_lds_floats<128, 3>()));
+  return L.lds + att <= 160 * 1024;
+}
+// a = the attn_output launch (attention partials as x, attn_merged = 0), t = its layer's attention (done_cnt unused);
+// sync = tl_fused_attn_sync_words() zeroed words shared by the launches of a model, tag in [1, tags_per_gen)
+int tl_launch_gemv_attn(const GemvArgs& a, const AttnArgs& t, unsigned* sync, unsigned tag, unsigned tags_per_gen,
+                        unsigned* err, hipStream_t s) {
+  TL_REQUIRE(tl_gemv_attn_supported(a, t), "gemv+attention: this launch has no folded form");
+  Launch L;
+  int role = GEMV_GENERIC;
+  bool classB = false, plain = false;
+  TL_TRY(gemv_plan(a, L, &role, &classB, &plain));
+  L.grid = g_num_cus;  // every CU: the attention tasks want workgroups of their own even where the projection has few rows
+  L.threads = tl_attn::ATT_THREADS;
+  L.wavesA = L.threads / 64;
+  FusedAttn fa = {};
+  fa.at = t;
+  fa.at.done_cnt = nullptr;
+  fa.at.ws = const_cast<float*>(a.attn_ws);
+  const int G = fused_attn_heads(t);
+  fa.at.zparts = (t.nh / t.nkv) / G;
+  if (fa.at.kv_row == 0) {
+    fa.at.kv_row = t.nkv * t.hd;
+    fa.at.kv_head = t.hd;
+  }
+  fa.count = sync;
+  fa.gen = sync + CHAIN_SHARD_WORDS;
+  fa.epoch = sync + 2 * CHAIN_SHARD_WORDS;
+  fa.tag = tag;
+  fa.tags_per_gen = tags_per_gen;
+  fa.err = err;
+  if (g_chain_stamps && g_chain_stamps_used + (size_t)L.grid * 8 <= g_chain_stamps_cap) {  // diagnostic run
+    fa.st = g_chain_stamps + g_chain_stamps_used;
+    g_chain_stamps_used += 256 * 8;
+  }
+  int rc = 0;
+  switch (a.seg[0].w.type) {
+    case TL_Q4_K: rc = gemv_attn_launch_shape<TL_Q4_K>(L, fa, G, s); break;
+    case TL_Q6_K: rc = gemv_attn_launch_shape<TL_Q6_K>(L, fa, G, s); break;
+    default: rc = gemv_attn_launch_shape<TL_Q8_0>(L, fa, G, s); break;
+  }
+  TL_TRY(rc);
+  TL_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- chain launches: host side -------------------------------------------------------------------------------------------
 // tl_chain_plan turns the arguments of one fused launch into a task of a chain launch (*ok = false: this launch has no chain
 // form -- an unfused route, flattened steps, a format without a chain body, a carried exchange); tasks of one chain are
 // uploaded by the caller (device array of ChainTask, TL_CHAIN_TASK_BYTES each) and run by tl_launch_chain.

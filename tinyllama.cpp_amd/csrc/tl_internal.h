@@ -220,6 +220,14 @@ bool tl_attn_split_supported(int nh, int nkv, int hd);
 size_t tl_attn_ws_floats(int nh, int hd);
 int tl_launch_attn_split(const AttnArgs& a, bool fuse, hipStream_t s);
 int tl_launch_attn_combine(const AttnArgs& a, hipStream_t s);
+// the attn_output GEMV that carries its layer's attention (tl_gemv.hip, gemv_attn_kernel)
+bool tl_gemv_attn_supported(const GemvArgs& a, const AttnArgs& t);
+// sync: tl_fused_attn_sync_words() zeroed words, in lines of TL_SYNC_LINE_WORDS: arrival counter | generation (advanced
+// once per step: tl_launch_chain_gen_bump) | epoch copies
+constexpr int TL_SYNC_LINE_WORDS = 32;
+size_t tl_fused_attn_sync_words();
+int tl_launch_gemv_attn(const GemvArgs& a, const AttnArgs& t, unsigned* sync, unsigned tag, unsigned tags_per_gen,
+                        unsigned* err, hipStream_t s);
 
 // batched-prefill GEMM on the matrix cores (tl_gemm.hip): activation planes = the FP32 activations split into
 // 1..3 bf16 planes [plane][padded tokens][cols]; terms = MFMAs per product (1, 3 or 6)

@@ -139,6 +139,14 @@ struct tl_model {
     unsigned* err() const { return sync + 1; }
     unsigned* counters(int first_task) const { return sync + 64 + tl_chain_sync_words(first_task); }
   } chain;
+  // The attention of a layer folded into the layer's attn_output launch (tl_gemv.hip, gemv_attn_kernel): four dependent
+  // launches per layer instead of five. sync: tl_fused_attn_sync_words() words + a line for the error word.
+  struct FusedAttention {
+    bool on = false;
+    unsigned* sync = nullptr;
+    unsigned* gen() const { return sync + TL_SYNC_LINE_WORDS; }
+    unsigned* err() const { return sync + tl_fused_attn_sync_words(); }
+  } fattn;
   int alt_seq = -1;  // >= 0: kc() / vc() address this sequence's region of the batch cache (prompt prefill of a sequence)
   float* kc(int l) const {
     return alt_seq >= 0 ? bt.kv + (((size_t)l * 2) * bt.max_batch + alt_seq) * kv_layer_elems
@@ -218,6 +226,7 @@ extern "C" int tl_model_free(tl_model* m) {
   if (m->graph_sampled) hipGraphDestroy(m->graph_sampled);
   hipFree(m->sparams);
   hipFree(m->sample_probs);
+  hipFree(m->fattn.sync);
   for (auto& l : m->layers) {
     for (auto*& w : l.q) tl_qweight_free(w);
     hipFree(l.attn_norm);
@@ -621,29 +630,32 @@ static int enqueue_embed(tl_model* m, hipStream_t s) {
   return tl_launch_dequant_gather(m->tok, m->state, 1, m->x, s);
 }
 // RoPE + KV write + attention of layer l (split partials in attn_ws, or the output in att)
+static AttnArgs args_attn_split(tl_model* m, int l) {
+  AttnArgs t = {};
+  t.q = m->q;
+  t.k = m->k;
+  t.v = m->v;
+  t.kc = m->kc(l);
+  t.vc = m->vc(l);
+  t.table = m->rope;
+  t.out = m->att;
+  t.ws = m->attn_ws;
+  t.nh = m->nh_l;
+  t.nkv = m->nkv_l;
+  t.hd = m->head_dim;
+  t.pos_dev = m->state + 1;
+  t.max_seq = m->cfg.max_position_embeddings;
+  t.scale = 1.0f / sqrtf((float)m->head_dim);
+  t.done_cnt = reinterpret_cast<unsigned*>(m->attn_ws + tl_attn_ws_floats(m->nh_l, m->head_dim));  // nh_l counters
+  return t;
+}
 static int enqueue_attention(tl_model* m, int l, hipStream_t s, StepProf* prof) {
   const tl_model_config& c = m->cfg;
   const int* pos_dev = m->state + 1;
   const float scale = 1.0f / sqrtf((float)m->head_dim);
   if (m->attn_split) {  // RoPE + KV write + split attention in one launch
-    AttnArgs t = {};
-    t.q = m->q;
-    t.k = m->k;
-    t.v = m->v;
-    t.kc = m->kc(l);
-    t.vc = m->vc(l);
-    t.table = m->rope;
-    t.out = m->att;
-    t.ws = m->attn_ws;
-    t.nh = m->nh_l;
-    t.nkv = m->nkv_l;
-    t.hd = m->head_dim;
-    t.pos_dev = pos_dev;
-    t.max_seq = c.max_position_embeddings;
-    t.scale = scale;
-    t.done_cnt = reinterpret_cast<unsigned*>(m->attn_ws + tl_attn_ws_floats(m->nh_l, m->head_dim));  // nh_l counters
     PROF_MARK(2);
-    TL_TRY(tl_launch_attn_split(t, true, s));
+    TL_TRY(tl_launch_attn_split(args_attn_split(m, l), true, s));
   } else {
     TL_TRY(tl_launch_rope_kv(m->q, m->k, m->v, m->kc(l), m->vc(l), m->rope, m->nh_l, m->nkv_l, m->head_dim, pos_dev,
                              c.max_position_embeddings, s));
@@ -657,6 +669,12 @@ static int enqueue_attention(tl_model* m, int l, hipStream_t s, StepProf* prof) 
 static int enqueue_attn_half(tl_model* m, int l, hipStream_t s, StepProf* prof) {
   TL_TRY(launch_proj(m, args_qkv(m, l), s));
   PROF_MARK(1);
+  if (m->fattn.on && !prof) {  // attention + attn_output in one launch
+    GemvArgs o = args_attn_out(m, l);
+    o.attn_merged = 0;
+    return tl_launch_gemv_attn(o, args_attn_split(m, l), m->fattn.sync, (unsigned)l + 1u,
+                               (unsigned)m->cfg.num_hidden_layers + 1u, m->fattn.err(), s);
+  }
   TL_TRY(enqueue_attention(m, l, s, prof));
   PROF_MARK(3);
   return launch_proj(m, args_attn_out(m, l), s);
@@ -718,6 +736,23 @@ static int plan_chain(tl_model* m) {
   m->chain.on = true;
   return 0;
 }
+// TL_FUSED_ATTN=1: fold every layer's attention into its attn_output launch, where that launch has the folded form
+static int plan_fused_attention(tl_model* m) {
+  m->fattn.on = false;
+  const char* e = getenv("TL_FUSED_ATTN");
+  if (!e || atoi(e) == 0) return 0;
+  if (m->tp != 1 || m->comm || m->has_f32 || !m->attn_split || m->chain.on) return 0;
+  for (int l = 0; l < m->cfg.num_hidden_layers; ++l) {
+    GemvArgs o = args_attn_out(m, l);
+    o.attn_merged = 0;
+    if (!tl_gemv_attn_supported(o, args_attn_split(m, l))) return 0;
+  }
+  const size_t bytes = sizeof(unsigned) * (tl_fused_attn_sync_words() + TL_SYNC_LINE_WORDS);
+  if (!m->fattn.sync) TL_HIP(hipMalloc(&m->fattn.sync, bytes));
+  TL_HIP(hipMemsetAsync(m->fattn.sync, 0, bytes, m->stream));
+  m->fattn.on = true;
+  return 0;
+}
 static int enqueue_sample(tl_model* m, hipStream_t s);
 static int enqueue_sample_topk(tl_model* m, hipStream_t s);
 static int enqueue_step_chain(tl_model* m, bool sampled) {
@@ -737,6 +772,15 @@ static int enqueue_step_chain(tl_model* m, bool sampled) {
 }
 // after a synchronised run: did a task of a chain launch give up waiting for its predecessor?
 static int chain_check(tl_model* m) {
+  if (m->fattn.on) {
+    unsigned flag = 0;
+    TL_HIP(hipMemcpy(&flag, m->fattn.err(), sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag != 0) {
+      TL_HIP(hipMemset(m->fattn.err(), 0, sizeof(flag)));
+      tl_set_error("tl_model: an attn_output launch timed out waiting for the attention it carries");
+      return 6;
+    }
+  }
   if (!m->chain.on) return 0;
   unsigned flag = 0;
   TL_HIP(hipMemcpy(&flag, m->chain.err(), sizeof(flag), hipMemcpyDeviceToHost));
@@ -768,6 +812,7 @@ static int enqueue_step(tl_model* m, StepProf* prof = nullptr, bool sampled = fa
   if (sampled) TL_TRY(enqueue_sample_topk(m, s));
   else TL_TRY(enqueue_sample(m, s));
   PROF_MARK(8);
+  if (m->fattn.on && !prof) TL_TRY(tl_launch_chain_gen_bump(m->fattn.gen(), s));
   return 0;
 }
 
@@ -995,6 +1040,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
   // waited in vain gets error 5 here and the group is out of step for good: free the models of all ranks.
   if (m->peer_on) TL_TRY(tl_peer_clear_error(m->peer, m->stream));
   TL_TRY(plan_chain(m));
+  TL_TRY(plan_fused_attention(m));
   TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));
   TL_TRY(enqueue_step(m));
   TL_HIP(hipStreamSynchronize(m->stream));

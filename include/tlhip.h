@@ -65,6 +65,14 @@ int tl_device_sync(void);
 int tl_qweight_upload(int type, const void* host_blocks, int rows, int cols, tl_qweight** out, void* stream);
 int tl_qweight_free(tl_qweight* w);
 int tl_qweight_info(const tl_qweight* w, int* type, int* rows, int* cols, size_t* device_bytes);
+/* Optional: keeps an expanded copy of the matrix for the batched paths (tl_matmul_q with num_tokens > 64, prefill, the
+ * multi-sequence decode step): the integers as one bf16 plane + FP32 scale words, 2.375 bytes per weight, from which the
+ * matrix cores are fed by LDS-DMA instead of unpacking the quantized planes in every workgroup. Results do not change by
+ * a bit. The counterpart of the reference's FP32 expansion, ensure_f32_concatenated_weights_loaded
+ * (weight_management.cpp:199-435; 4 bytes per weight there). tl_model_finalize does this for a model's matrices when the
+ * copy is at most a quarter of the device's memory (TL_PREFILL_PLANES=0 / 1: never / always). tl_qweight_free drops it.
+ * *expanded_bytes (may be NULL): device bytes of the copy (0: this format has none -- F32 / BF16 matrices). */
+int tl_qweight_expand(tl_qweight* w, size_t* expanded_bytes, void* stream);
 
 /* Bit-exact dequantization on the device (parity hook for dequantize_q4_k_m / dequantize_q6_k /
  * dequantize_q8_0_block / dequantize_q8_k, quantization.cpp:171-266, 1009-1052): rows [row0, row0+nrows)

@@ -40,6 +40,10 @@ int tl_model_profile_decode(tl_model* m, int first_token, int start_pos, int n_s
  * step's all-reduce of f32[hidden] of a linked tensor-parallel shard (a collective call: every rank makes it). */
 int tl_model_bench_kernel(tl_model* m, int kind, int iters, int warmup, float* avg_us_out, double* bytes_per_launch_out);
 
+/* Diagnostic hook (no counterpart in the reference): launches of the expanded-plane GEMM kernel (tl_qweight_expand) so far
+ * in this process: lets a test prove which kernel formed a result. */
+int tl_debug_gemm_px_launches(long long* count_out);
+
 /* ---- libtlhip_tools.so (csrc/tl_stream.hip; built beside libtlhip.so, not part of it): a measured negative result kept
  * for the record -- the persistent ring-loader engine of round 2. */
 /* Measurement / parity hook (no counterpart in the reference): y_i = W_i x through the ring-loader engine (tl_stream.hip),

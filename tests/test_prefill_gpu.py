@@ -130,6 +130,57 @@ def test_few_tokens_take_the_multi_vector_gemv(E, pkg, oracle, name, rows, cols,
         assert np.array_equal(y[i], w.matvec(x[i])), i
 
 
+@pytest.mark.parametrize("name,rows,cols,T", [
+    ("q4_k", 512, 1024, 65), ("q4_k", 333, 512, 130), ("q4_k", 4096, 4096, 512), ("q4_k", 1024, 14336, 128),
+    ("q6_k", 256, 1024, 200), ("q6_k", 4100, 4096, 257), ("q8_0", 192, 512, 129), ("q8_0", 2048, 2048, 384),
+    ("q8_k", 128, 768, 140), ("q6_k", 1000, 256, 100)])
+def test_expanded_plane_gemm_is_bit_identical(E, pkg, oracle, monkeypatch, name, rows, cols, T):
+    """tl_qweight_expand: the batched GEMM fed by LDS-DMA from the resident bf16 integer plane + scale words
+    (gemm_px_kernel, 256-row tiles, producers that only issue DMAs) forms exactly the sums of the kernel that unpacks the
+    quantized planes in every workgroup (gemm_qi_ws_kernel): every format, row counts off the 256-row tile, K splits (few
+    tiles) and none (many), token counts off the 128-token tile, 3- and 6-term products -- bit for bit, and within the GEMM
+    bar of the oracle."""
+    from tinyllama_cpp_amd.capi import lib, check
+    t, S = TYPES[name], pkg.synth
+    rng = np.random.default_rng(11 * rows + cols + T)
+    blocks = S.random_blocks(t, rows * cols // S.BLOCK_ELEMS[t], rng, w_std=1.0 / np.sqrt(cols))
+    x = rng.standard_normal((T, cols)).astype(np.float32)
+    sc = np.ones((T, 1), np.float32)
+    sc[0], sc[-1] = 2.0 ** -10, 64.0
+    x *= sc
+    w = E.QWeight(t, blocks, rows, cols)
+    before = {}
+    for terms in (6, 3):
+        check(lib().tl_gemm_set_terms(terms))
+        before[terms] = _matmul(E, w, x)
+    def px_launches():
+        import ctypes as C
+        n = C.c_longlong()
+        check(lib().tl_debug_gemm_px_launches(C.byref(n)))
+        return n.value
+
+    n0 = px_launches()
+    nbytes = w.expand()
+    mt, nk = (rows + 255) // 256, cols // 32
+    assert nbytes == mt * nk * (256 * 32 * 2 + 3 * 256 * 4)
+    for terms in (6, 3):
+        check(lib().tl_gemm_set_terms(terms))
+        y = _matmul(E, w, x)
+        assert np.array_equal(y, before[terms]), (terms, np.abs(y - before[terms]).max())
+        n1 = px_launches()
+        monkeypatch.setenv("TL_GEMM_PX", "0")  # the planes are there but ignored: the unpacking kernel again
+        assert np.array_equal(_matmul(E, w, x), before[terms])
+        monkeypatch.delenv("TL_GEMM_PX")
+        assert px_launches() == n1
+    assert n1 == n0 + 2  # (one launch per product: the expanded-plane kernel formed y)
+    check(lib().tl_gemm_set_terms(6))
+    if rows * cols * T <= 4096 * 4096 * 64:  # (the oracle's Kahan-double dots: seconds)
+        want = oracle.matmul_q_batch(t, blocks, x, T, rows, cols)
+        assert close(y / sc, want / sc, TOL[3]).all()
+        assert close(_matmul(E, w, x) / sc, want / sc, TOL[6]).all()
+    w.free()
+
+
 def test_gemm_edge_scales(E, pkg, oracle):
     """fp16 sub-normal / zero / negative super-scales inside an MFMA tile."""
     from tinyllama_cpp_amd.capi import lib, check

@@ -45,6 +45,7 @@ SIGNATURES = {
     "tl_qweight_upload": [C.c_int, _vp, C.c_int, C.c_int, C.POINTER(C.c_void_p), _vp],
     "tl_qweight_free": [_vp],
     "tl_qweight_info": [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(_sz)],
+    "tl_qweight_expand": [_vp, C.POINTER(_sz), _vp],
     "tl_dequantize_rows": [_vp, C.c_int, C.c_int, _fp, _vp],
     "tl_matvec_q": [_vp, _fp, _fp, _vp],
     "tl_matmul_q": [_vp, _fp, _fp, C.c_int, _vp],
@@ -105,6 +106,7 @@ DEBUG_SIGNATURES = {
     "tl_model_profile_decode": [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp],
     "tl_model_bench_kernel": [_vp, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_double)],
     "tl_chain_set_stamps": [_vp, _sz],
+    "tl_debug_gemm_px_launches": [C.POINTER(C.c_longlong)],
 }
 
 # libtlhip_tools.so (csrc/tl_stream.hip): experiments kept out of the product library; declared in include/tlhip_debug.h

@@ -27,7 +27,9 @@
 //     weight-row tiles of ONE token panel, so a panel's activation planes (<= 3 MB) stay in that XCD's L2.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
+#include <unordered_map>
 
 #include "tl_internal.h"
 
@@ -711,6 +713,230 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(MSe
   }
 }
 
+// ---- the expanded-plane form: prefill planes resident in HBM, the matrix cores fed by LDS-DMA ------------------------------
+// Measured (profiles/r03_d): in gemm_qi_ws_kernel the producers' unpack and the consumers' MFMA + scale FMAs share each
+// SIMD's issue slots; either role alone needs ~75 % of the step. The reference keeps an FP32 expansion of every matrix on the
+// device for its batched path (ensure_f32_concatenated_weights_loaded, weight_management.cpp; cuBLAS reads 4 bytes per
+// weight); with 288 GB of HBM this backend can afford the same trade at half the bytes: tl_gemm_expand() writes, once per
+// matrix, exactly what the producers of gemm_qi_ws_kernel would write into LDS for every (256-row tile, 32-column step) --
+// the integers as ONE bf16 plane, chunk swizzle applied, and the FP32 scale words -- as contiguous 16 KB + 3 KB records.
+// The kernel's producer waves then issue nothing but global_load_lds (LDS-DMA: no VGPRs, no VALU, no LDS write
+// instructions), three steps deep in a ring of LDS buffers, and the eight consumer waves run the same MFMA / scale
+// sequence as gemm_qi_ws_kernel on the same operands: the results are bit-identical to that kernel's.
+// Producers and consumers stay separate waves for a second reason: hipcc makes every LDS read that follows an LDS-DMA
+// issue in the same wave wait for that DMA (it cannot tell the buffers apart), which would serialise a wave that did both.
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* glb_vptr;
+constexpr int PX_BM = 256, PX_BN = 128, PX_NB = 3;
+constexpr int PX_PW = 4, PX_CW = 8;                  // producer / consumer waves
+constexpr int PX_THREADS = 64 * (PX_PW + PX_CW);
+constexpr int PX_SC = 3 * PX_BM;                     // scale words per (row tile, step): sA [256][2] | sB [256]
+constexpr size_t PX_WBYTES = (size_t)PX_BM * LROW * sizeof(__bf16);   // 16 KB
+constexpr size_t PX_XBYTES = (size_t)PX_BN * LROW * sizeof(__bf16);   // 8 KB per activation plane
+template <int NPX>
+constexpr size_t px_buf_bytes() { return PX_WBYTES + NPX * PX_XBYTES + PX_SC * sizeof(float) + 1024; }  // (+ sx: 512 B used)
+
+// one thread per row of a 256-row tile; grid (steps, row tiles)
+template <int TYPE>
+__global__ __launch_bounds__(PX_BM) void px_expand_kernel(QW w, __bf16* __restrict__ q, float* __restrict__ sc, int nk) {
+#pragma clang fp contract(off)
+  const int k = blockIdx.x, mt = blockIdx.y, r = threadIdx.x;
+  const int grow = mt * PX_BM + r;
+  __bf16* qb = q + ((size_t)mt * nk + k) * (PX_BM * LROW);
+  float* fb = sc + ((size_t)mt * nk + k) * PX_SC;
+  if (grow >= w.rows) {  // padding rows: zeros
+    const bf16x8 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+    for (int wq = 0; wq < 4; ++wq) *reinterpret_cast<bf16x8*>(qb + lds_off(r, wq)) = z;
+    fb[2 * r] = 0.f;
+    fb[2 * r + 1] = 0.f;
+    fb[2 * PX_BM + r] = 0.f;
+    return;
+  }
+  fb[2 * PX_BM + r] = 0.f;
+#pragma unroll
+  for (int wq = 0; wq < 4; ++wq) {
+    const Raw8 raw = load8<TYPE>(w, grow, k, wq);
+    *reinterpret_cast<bf16x8*>(qb + lds_off(r, wq)) = unpack8<TYPE>(raw, wq);
+    if (TYPE == TL_Q4_K) {  // (the same separately rounded products as gemm_qi_ws_kernel's producers)
+      if (wq == 0) {
+        const int c = k & 7;
+        const float d = h2f(raw.h[0] & 0xffffu), dmin = h2f(raw.h[0] >> 16);
+        const unsigned scv = ((raw.h[1] >> (4 * c)) & 15u) | (((raw.h[3] >> (2 * c)) & 3u) << 4);
+        const unsigned mn = ((raw.h[2] >> (4 * c)) & 15u) | (((raw.h[3] >> (16 + 2 * c)) & 3u) << 4);
+        const float d1 = __fmul_rn(d, (float)scv);
+        fb[2 * r] = d1;
+        fb[2 * r + 1] = d1;
+        fb[2 * PX_BM + r] = __fmul_rn(dmin, (float)mn);
+      }
+    } else if (TYPE == TL_Q6_K) {
+      if ((wq & 1) == 0) fb[2 * r + (wq >> 1)] = __fmul_rn(h2f(raw.h[1]), (float)(int)(signed char)(raw.h[0] & 0xffu));
+    } else {
+      if (wq == 0) {
+        const float d = h2f_scale(raw.h[0]);
+        fb[2 * r] = d;
+        fb[2 * r + 1] = d;
+      }
+    }
+  }
+}
+
+struct PSegs {
+  const __bf16* q[3];
+  const float* sc[3];
+  float* y[3];
+  int M[3];
+  int mt_end[3];  // cumulative 256-row tile counts
+  int S[3];       // K slices of each matrix
+};
+template <int TYPE, int NPX>
+__global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
+                                                             const float* __restrict__ xsum, int tpad,
+                                                             const float* __restrict__ resid, int T, int K, int mtiles,
+                                                             int ntiles) {
+  constexpr int BM = PX_BM, BN = PX_BN, NI = 2, MI = 2;
+  constexpr bool PER16 = TYPE == TL_Q6_K;
+  constexpr size_t BUF = px_buf_bytes<NPX>();
+  constexpr int XPL = BN * LROW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int total = mtiles * ntiles;
+  int tile = blockIdx.x;
+  if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
+  const int nt = tile / mtiles;
+  int mt = tile - nt * mtiles;
+  const int seg = (mt >= segs.mt_end[0]) + (mt >= segs.mt_end[1]);
+  if (seg) mt -= segs.mt_end[seg - 1];
+  const int nslices = segs.S[seg];
+  if ((int)blockIdx.y >= nslices) return;  // (uniform over the workgroup, before any barrier)
+  const int M = segs.M[seg];
+  float* __restrict__ y = segs.y[seg];
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nk_all = K / GB_K, kper = (nk_all + nslices - 1) / nslices;
+  const int kbase = (int)blockIdx.y * kper;
+  const int nk = nk_all - kbase < kper ? nk_all - kbase : kper;
+  if (nslices > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wave >= PX_CW) {
+    // ---------------- producers: LDS-DMA only ----------------
+    const int pw = wave - PX_CW;
+    constexpr int XI = NPX * 2;       // activation DMAs per wave and step (NPX planes x 8 sixteen-token groups over 4 waves)
+    constexpr int PER = 4 + XI + 1;   // DMAs per wave and step
+    const __bf16* wsrc = segs.q[seg] + ((size_t)mt * nk_all + kbase) * (BM * LROW) + (size_t)(pw * 4) * 512 + lane * 8;
+    const float* msrc = pw < 3 ? segs.sc[seg] + ((size_t)mt * nk_all + kbase) * PX_SC + pw * 256 + lane * 4
+                               : xsum + (size_t)kbase * tpad + n0 + (lane & 31) * 4;
+    const size_t mstep = pw < 3 ? (size_t)PX_SC : (size_t)tpad;
+    const __bf16* xsrc[XI];
+    int xdst[XI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+      const int idx = pw * XI + j, p = idx >> 3, i = idx & 7;
+      const int row = i * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
+      xsrc[j] = xp + (size_t)p * plane_stride + (size_t)(n0 + row) * K + (size_t)kbase * GB_K + chunk * 8;
+      xdst[j] = (int)(PX_WBYTES + p * PX_XBYTES + i * 1024);
+    }
+    const int mdst = (int)(PX_WBYTES + NPX * PX_XBYTES) + (pw < 3 ? pw * 1024 : PX_SC * 4);
+    auto issue = [&](int kk) {
+      unsigned char* b = lds_raw + (size_t)(kk % PX_NB) * BUF;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((glb_vptr)(wsrc + (size_t)kk * (BM * LROW) + i * 512), (lds_vptr)(b + (pw * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < XI; ++j)
+        __builtin_amdgcn_global_load_lds((glb_vptr)(xsrc[j] + (size_t)kk * GB_K), (lds_vptr)(b + xdst[j]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_vptr)(msrc + (size_t)kk * mstep), (lds_vptr)(b + mdst), 16, 0, 0);
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    for (int kk = 0; kk < nk; ++kk) {
+      // step kk has landed (the DMAs of step kk + 1 may still be in flight); meet the consumers, who are through with step
+      // kk - 1: its buffer takes step kk + 2
+      if (kk + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kk + 2 < nk) issue(kk + 2);
+    }
+    return;
+  }
+  // ---------------- consumers: wave = 64 tokens x 64 rows ----------------
+  const int wm = wave & 3, wn = wave >> 2;
+  const int fr = lane & 31, fh = lane >> 5;
+  const int lrow0 = wm * 64 + fr;
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int kk = 0; kk < nk; ++kk) {
+    __syncthreads();
+    const unsigned char* b = lds_raw + (size_t)(kk % PX_NB) * BUF;
+    const __bf16* wb = reinterpret_cast<const __bf16*>(b);
+    const __bf16* xb = reinterpret_cast<const __bf16*>(b + PX_WBYTES);
+    const float* fb = reinterpret_cast<const float*>(b + PX_WBYTES + NPX * PX_XBYTES);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      f32x16 t[MI];
+#pragma unroll
+      for (int j = 0; j < MI; ++j) t[j] = zero;
+#pragma unroll
+      for (int k16 = 0; k16 < 2; ++k16) {
+        bf16x8 a[NPX];
+#pragma unroll
+        for (int p = 0; p < NPX; ++p)
+          a[p] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 * i + fr, k16 * 2 + fh));
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const bf16x8 bq = *reinterpret_cast<const bf16x8*>(wb + lds_off(lrow0 + 32 * j, k16 * 2 + fh));
+#pragma unroll
+          for (int p = NPX - 1; p >= 0; --p) t[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p], bq, t[j], 0, 0, 0);  // smallest plane first
+          if (PER16) {
+            const float sa = fb[2 * (lrow0 + 32 * j) + k16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(sa, t[j][e], acc[i][j][e]);
+            t[j] = zero;
+          }
+        }
+      }
+      if (!PER16) {
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const float sa = fb[2 * (lrow0 + 32 * j)];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(sa, t[j][e], acc[i][j][e]);
+        }
+      }
+      if (TYPE == TL_Q4_K) {
+        const float* sx = fb + PX_SC;
+        f32x4 v[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(sx + wn * 64 + 32 * i + 8 * g4 + 4 * fh);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) {
+          const float nsb = -fb[2 * BM + lrow0 + 32 * j];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(nsb, v[e >> 2][e & 3], acc[i][j][e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MI; ++j) {
+    const int m = m0 + lrow0 + 32 * j;
+    if (m >= M) continue;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        if (t < T) {
+          const size_t o = (size_t)t * M + m;
+          y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
+        }
+      }
+  }
+}
+
 // ---- the direct form for few tokens (multi-sequence decode steps, short prompts) ----------------------------------------
 // With <= 64 tokens a weight byte meets so few MFMAs that the kernel above is bound by its four producer waves (byte
 // unpack + LDS write of every weight: the whole weight set passes in ~8 ms whatever the token count). Here the weights
@@ -1268,9 +1494,70 @@ static bool qi_narrow_always() {
   }
   return v != 0;
 }
+// ---- expanded prefill planes: registry (keyed by the matrix's first plane pointer) and launch ------------------------------
+struct PxEntry {
+  __bf16* q;
+  float* sc;
+  size_t bytes;
+};
+static std::mutex g_px_mu;
+static std::atomic<long> g_px_launches{0};
+static std::unordered_map<const void*, PxEntry> g_px;
+static bool px_enabled() {  // TL_GEMM_PX=0: ignore the expanded planes (A/B runs; read at every launch)
+  const char* e = getenv("TL_GEMM_PX");
+  return e ? atoi(e) != 0 : true;
+}
+static bool px_lookup(const QW& w, PxEntry* out) {
+  std::lock_guard<std::mutex> lock(g_px_mu);
+  auto it = g_px.find(w.p0);
+  if (it == g_px.end()) return false;
+  *out = it->second;
+  return true;
+}
+// the expanded-plane launch of n <= 3 matrices (same format and width) with S[i] K slices each; false: not every matrix has
+// its planes (the caller takes the unpacking kernel)
+template <int TYPE, int NPX>
+int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, const float* resid, int T,
+                   hipStream_t s, bool* done) {
+  *done = false;
+  if (!px_enabled()) return 0;
+  PxEntry e[3];
+  for (int i = 0; i < n; ++i)
+    if (!px_lookup(w[i], &e[i])) return 0;
+  constexpr size_t lds = PX_NB * px_buf_bytes<NPX>();
+  static_assert(lds <= 160 * 1024, "three LDS buffers per workgroup");
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_px_kernel<TYPE, NPX>, (int)lds, lds_raised));
+  const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
+  const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + PX_BN - 1) / PX_BN;
+  PSegs g = {};
+  int mt = 0, smax = 1;
+  for (int i = 0; i < 3; ++i) {
+    const int k = i < n ? i : n - 1;  // (unused slots repeat the last matrix; their tile range is empty)
+    g.q[i] = e[k].q;
+    g.sc[i] = e[k].sc;
+    g.y[i] = out[k];
+    g.M[i] = w[k].rows;
+    g.S[i] = S[k];
+    if (i < n) mt += (w[i].rows + PX_BM - 1) / PX_BM;
+    g.mt_end[i] = mt;
+    if (S[k] > smax) smax = S[k];
+  }
+  gemm_px_kernel<TYPE, NPX><<<dim3(mt * ntiles, smax), dim3(PX_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, w[0].cols, mt, ntiles);
+  TL_HIP(hipGetLastError());
+  ++g_px_launches;
+  *done = true;
+  return 0;
+}
+
 // n matrices in one launch (gemm_qi_ws_kernel NSEG = 3); S[i] slices for matrix i, outputs / partial tiles in out[i]
 template <int TYPE, int NPX, int BN, int BM>
 int launch_gemm_qi_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, int T, hipStream_t s) {
+  if constexpr (BN == GB_N && BM == 128) {  // the same sums from the expanded planes, where every matrix has them
+    bool done = false;
+    TL_TRY((launch_gemm_px<TYPE, NPX>(w, n, xp, ps, out, S, nullptr, T, s, &done)));
+    if (done) return 0;
+  }
   constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
   static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
   TL_TRY(tl_raise_lds_limit(gemm_qi_ws_kernel<TYPE, NPX, BN, BM, 3>, (int)lds, lds_raised));
@@ -1304,6 +1591,16 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   float* part = nullptr;
   bool deferred = false;
   TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
+  if constexpr (BN == GB_N && BM == 128) {  // the same sums (same K slices) from the expanded planes, if this matrix has them
+    bool done = false;
+    float* o = S == 1 ? y : part;
+    TL_TRY((launch_gemm_px<TYPE, NPX>(&w, 1, xp, ps, &o, &S, S == 1 ? resid : nullptr, T, s, &done)));
+    if (done) {
+      if (S > 1) ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
+      TL_HIP(hipGetLastError());
+      return 0;
+    }
+  }
   MSegs g = {};
   g.w[0] = w;
   g.y[0] = S == 1 ? y : part;
@@ -1504,6 +1801,67 @@ int g_gemm_terms = 6;
 }  // namespace
 
 int tl_gemm_default_terms() { return g_gemm_terms; }
+
+// ---- expanded prefill planes (see gemm_px_kernel) --------------------------------------------------------------------------
+size_t tl_gemm_expanded_bytes(int rows, int cols) {
+  const size_t mtiles = (size_t)(rows + PX_BM - 1) / PX_BM, nk = (size_t)cols / GB_K;
+  return mtiles * nk * (PX_WBYTES + PX_SC * sizeof(float));
+}
+bool tl_gemm_expandable(const tl_qweight* w) {
+  return w && (w->type == TL_Q4_K || w->type == TL_Q6_K || w->type == TL_Q8_0 || w->type == TL_Q8_K) && w->cols % 64 == 0 &&
+         w->rows > 0;
+}
+int tl_gemm_expand(const tl_qweight* w, hipStream_t s) {
+  TL_REQUIRE(tl_gemm_expandable(w), "tl_gemm_expand: this matrix has no expanded form");
+  {
+    std::lock_guard<std::mutex> lock(g_px_mu);
+    if (g_px.count(w->p0)) return 0;
+  }
+  const int mtiles = (w->rows + PX_BM - 1) / PX_BM, nk = w->cols / GB_K;
+  const size_t qbytes = (size_t)mtiles * nk * PX_WBYTES, bytes = tl_gemm_expanded_bytes(w->rows, w->cols);
+  void* base = nullptr;
+  hipError_t e = hipMalloc(&base, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    tl_set_error("tl_gemm_expand: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return 1;
+  }
+  PxEntry ent = {static_cast<__bf16*>(base), reinterpret_cast<float*>(static_cast<unsigned char*>(base) + qbytes), bytes};
+  const QW v = qw_view(w);
+  const dim3 grid(nk, mtiles);
+  switch (w->type) {
+    case TL_Q4_K: px_expand_kernel<TL_Q4_K><<<grid, PX_BM, 0, s>>>(v, ent.q, ent.sc, nk); break;
+    case TL_Q6_K: px_expand_kernel<TL_Q6_K><<<grid, PX_BM, 0, s>>>(v, ent.q, ent.sc, nk); break;
+    case TL_Q8_0: px_expand_kernel<TL_Q8_0><<<grid, PX_BM, 0, s>>>(v, ent.q, ent.sc, nk); break;
+    default: px_expand_kernel<TL_Q8_K><<<grid, PX_BM, 0, s>>>(v, ent.q, ent.sc, nk); break;
+  }
+  e = hipGetLastError();
+  if (e != hipSuccess) {
+    hipFree(base);
+    tl_set_error("tl_gemm_expand: launch failed: %s", hipGetErrorString(e));
+    return 1;
+  }
+  std::lock_guard<std::mutex> lock(g_px_mu);
+  g_px[w->p0] = ent;
+  return 0;
+}
+// called by tl_qweight_free: drops the matrix's expanded planes, if any
+void tl_gemm_expand_release(const tl_qweight* w) {
+  if (!w) return;
+  PxEntry ent = {};
+  {
+    std::lock_guard<std::mutex> lock(g_px_mu);
+    auto it = g_px.find(w->p0);
+    if (it == g_px.end()) return;
+    ent = it->second;
+    g_px.erase(it);
+  }
+  hipFree(ent.q);
+}
+bool tl_gemm_expanded(const tl_qweight* w) {
+  std::lock_guard<std::mutex> lock(g_px_mu);
+  return w && g_px.count(w->p0) != 0;
+}
 size_t tl_gemm_padded_tokens(int T) { return (size_t)((T + GB_N - 1) / GB_N) * GB_N; }
 // bytes of an activation-plane buffer with plane_stride = padded tokens x columns: three bf16 planes + the FP32 sums of
 // every 32-column block
@@ -1663,6 +2021,22 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
   for (int i = 0; i < n; ++i)
     if (defer && defer[i]) defer[i]->got = S[i] > 1 ? GemmParts{out[i], (size_t)T * w[i].rows, S[i]} : GemmParts{nullptr, 0, 0};
   *merged = true;
+  return 0;
+}
+
+extern "C" int tl_qweight_expand(tl_qweight* w, size_t* expanded_bytes, void* stream) {
+  TL_REQUIRE(w, "tl_qweight_expand: null handle");
+  if (expanded_bytes) *expanded_bytes = 0;
+  if (!tl_gemm_expandable(w)) return 0;
+  TL_TRY(tl_gemm_expand(w, static_cast<hipStream_t>(stream)));
+  if (expanded_bytes) *expanded_bytes = tl_gemm_expanded_bytes(w->rows, w->cols);
+  return 0;
+}
+
+// Diagnostic hook (include/tlhip_debug.h): launches of the expanded-plane kernel so far in this process
+extern "C" int tl_debug_gemm_px_launches(long long* count_out) {
+  TL_REQUIRE(count_out, "tl_debug_gemm_px_launches: null argument");
+  *count_out = g_px_launches.load();
   return 0;
 }
 

@@ -232,6 +232,14 @@ int tl_launch_gemv_attn(const GemvArgs& a, const AttnArgs& t, unsigned* sync, un
 // batched-prefill GEMM on the matrix cores (tl_gemm.hip): activation planes = the FP32 activations split into
 // 1..3 bf16 planes [plane][padded tokens][cols]; terms = MFMAs per product (1, 3 or 6)
 int tl_gemm_default_terms();
+// expanded prefill planes (tl_gemm.hip, gemm_px_kernel): a resident bf16 integer plane + FP32 scale words per matrix
+// (2.375 bytes per weight), from which the batched GEMM is fed by LDS-DMA instead of unpacking the quantized planes in
+// every workgroup; same results. tl_qweight_free releases them.
+size_t tl_gemm_expanded_bytes(int rows, int cols);
+bool tl_gemm_expandable(const tl_qweight* w);
+bool tl_gemm_expanded(const tl_qweight* w);
+int tl_gemm_expand(const tl_qweight* w, hipStream_t s);
+void tl_gemm_expand_release(const tl_qweight* w);
 size_t tl_gemm_padded_tokens(int T);
 size_t tl_gemm_planes_bytes(size_t plane_stride);  // three bf16 planes + FP32 block sums
 // mode 0: planes = split(x[T][K]); 1: split(rmsnorm_batch(x, aux = weight[K], eps)); 2: split(swiglu(x, aux[T][K]))

@@ -141,6 +141,7 @@ struct tl_model {
   } chain;
   // The attention of a layer folded into the layer's attn_output launch (tl_gemv.hip, gemv_attn_kernel): four dependent
   // launches per layer instead of five. sync: tl_fused_attn_sync_words() words + a line for the error word.
+  size_t expanded_bytes = 0;  // device bytes of the expanded prefill planes this model's finalize added (tl_gemm_expand)
   struct FusedAttention {
     bool on = false;
     unsigned* sync = nullptr;
@@ -736,6 +737,30 @@ static int plan_chain(tl_model* m) {
   m->chain.on = true;
   return 0;
 }
+// Expanded prefill planes for every quantized matrix of the model (tl_gemm.hip, gemm_px_kernel), when they are affordable:
+// at most a quarter of the device's memory and what is free now less 4 GiB (TL_PREFILL_PLANES=0 / 1: never / always).
+static int expand_prefill_planes(tl_model* m) {
+  const char* e = getenv("TL_PREFILL_PLANES");
+  const int mode = e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  if (mode == 0) return 0;
+  std::vector<const tl_qweight*> ws;
+  for (auto& l : m->layers)
+    for (auto* w : l.q)
+      if (tl_gemm_expandable(w)) ws.push_back(w);
+  if (tl_gemm_expandable(m->out)) ws.push_back(m->out);
+  size_t need = 0;
+  for (auto* w : ws)
+    if (!tl_gemm_expanded(w)) need += tl_gemm_expanded_bytes(w->rows, w->cols);
+  if (mode < 0) {
+    size_t free_b = 0, total_b = 0;
+    TL_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (need > total_b / 4 || need + ((size_t)4 << 30) > free_b) return 0;
+  }
+  for (auto* w : ws) TL_TRY(tl_gemm_expand(w, m->stream));
+  m->expanded_bytes = need;
+  return 0;
+}
+
 // TL_FUSED_ATTN=1: fold every layer's attention into its attn_output launch, where that launch has the folded form
 static int plan_fused_attention(tl_model* m) {
   m->fattn.on = false;
@@ -1039,6 +1064,7 @@ extern "C" int tl_model_finalize(tl_model* m) {
   // (TL_TP_PEER_TIMEOUT_MS, 5 s by default) of the others; put a host barrier before it (bench.py does). A rank that
   // waited in vain gets error 5 here and the group is out of step for good: free the models of all ranks.
   if (m->peer_on) TL_TRY(tl_peer_clear_error(m->peer, m->stream));
+  TL_TRY(expand_prefill_planes(m));
   TL_TRY(plan_chain(m));
   TL_TRY(plan_fused_attention(m));
   TL_TRY(set_state(m, 0, 0, 1.0f, nullptr, 0));

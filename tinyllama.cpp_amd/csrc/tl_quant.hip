@@ -222,6 +222,7 @@ extern "C" int tl_qweight_upload(int type, const void* host_blocks, int rows, in
 
 extern "C" int tl_qweight_free(tl_qweight* w) {
   if (!w) return 0;
+  tl_gemm_expand_release(w);
   hipError_t e = hipFree(w->base);
   delete w;
   TL_HIP(e);

@@ -77,6 +77,13 @@ class QWeight:
         check(lib().tl_qweight_info(self.h, None, None, None, C.byref(n)), "tl_qweight_info")
         return n.value
 
+    def expand(self):
+        """Keep the expanded prefill planes of this matrix (tl_qweight_expand); returns their device bytes."""
+        n = C.c_size_t()
+        check(lib().tl_qweight_expand(self.h, C.byref(n), None), "tl_qweight_expand")
+        check(lib().tl_device_sync(), "sync")
+        return n.value
+
     def dequantize(self, row0=0, nrows=None):
         nrows = self.rows - row0 if nrows is None else nrows
         out = DeviceBuffer(max(4, 4 * nrows * self.cols))

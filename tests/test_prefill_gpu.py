@@ -159,6 +159,7 @@ def test_expanded_plane_gemm_is_bit_identical(E, pkg, oracle, monkeypatch, name,
         check(lib().tl_debug_gemm_px_launches(C.byref(n)))
         return n.value
 
+    monkeypatch.setenv("TL_GEMM_PX_SLICES", "0")  # the unpacking kernel's K slices: then the sums agree bit for bit
     n0 = px_launches()
     nbytes = w.expand()
     mt, nk = (rows + 255) // 256, cols // 32
@@ -173,11 +174,22 @@ def test_expanded_plane_gemm_is_bit_identical(E, pkg, oracle, monkeypatch, name,
         monkeypatch.delenv("TL_GEMM_PX")
         assert px_launches() == n1
     assert n1 == n0 + 2  # (one launch per product: the expanded-plane kernel formed y)
+    monkeypatch.setenv("TL_GEMM_PX2", "1")  # the all-consumer variant of the kernel: the same sums again
+    for terms in (6, 3):
+        check(lib().tl_gemm_set_terms(terms))
+        assert np.array_equal(_matmul(E, w, x), before[terms]), terms
+    monkeypatch.delenv("TL_GEMM_PX2")
+    assert px_launches() == n1 + 2
     check(lib().tl_gemm_set_terms(6))
+    # the kernel's own K slices (the default): other partial sums, FP32 rounding apart
+    monkeypatch.delenv("TL_GEMM_PX_SLICES")
+    y6 = _matmul(E, w, x)
+    rowmax = np.maximum(sc, np.abs(before[6]).max(axis=1, keepdims=True))
+    assert (np.abs(y6 - before[6]) <= 2e-5 * rowmax).all()
     if rows * cols * T <= 4096 * 4096 * 64:  # (the oracle's Kahan-double dots: seconds)
         want = oracle.matmul_q_batch(t, blocks, x, T, rows, cols)
         assert close(y / sc, want / sc, TOL[3]).all()
-        assert close(_matmul(E, w, x) / sc, want / sc, TOL[6]).all()
+        assert close(y6 / sc, want / sc, TOL[6]).all()
     w.free()
 
 

@@ -20,10 +20,13 @@ def main():
     from tinyllama_cpp_amd.capi import lib, check
     E.init(0)
     T = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    expand = len(sys.argv) > 2 and sys.argv[2] == "px"  # the expanded-plane kernel (tl_qweight_expand) instead
     rng = np.random.default_rng(0)
     for rows, cols in ((14336, 4096), (4096, 14336)):
         blocks = S.random_blocks(S.Q4_K, rows * cols // 256, rng, w_std=0.02)
         w = E.QWeight(S.Q4_K, blocks, rows, cols)
+        if expand:
+            w.expand()
         x = E.DeviceBuffer.from_numpy(rng.standard_normal((T, cols)).astype(np.float32))
         y = E.DeviceBuffer(4 * T * rows)
         for _ in range(3):

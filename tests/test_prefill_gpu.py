@@ -174,12 +174,10 @@ def test_expanded_plane_gemm_is_bit_identical(E, pkg, oracle, monkeypatch, name,
         monkeypatch.delenv("TL_GEMM_PX")
         assert px_launches() == n1
     assert n1 == n0 + 2  # (one launch per product: the expanded-plane kernel formed y)
-    monkeypatch.setenv("TL_GEMM_PX2", "1")  # the all-consumer variant of the kernel: the same sums again
-    for terms in (6, 3):
-        check(lib().tl_gemm_set_terms(terms))
-        assert np.array_equal(_matmul(E, w, x), before[terms]), terms
-    monkeypatch.delenv("TL_GEMM_PX2")
-    assert px_launches() == n1 + 2
+    monkeypatch.setenv("TL_GEMM_PX_BM", "128")  # half a record per workgroup (the form taken for few row tiles): same sums
+    assert np.array_equal(_matmul(E, w, x), before[3])
+    monkeypatch.delenv("TL_GEMM_PX_BM")
+    assert px_launches() == n1 + 1
     check(lib().tl_gemm_set_terms(6))
     # the kernel's own K slices (the default): other partial sums, FP32 rounding apart
     monkeypatch.delenv("TL_GEMM_PX_SLICES")

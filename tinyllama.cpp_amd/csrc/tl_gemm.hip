@@ -723,6 +723,11 @@ __global__ __launch_bounds__(WS_THREADS, TL_QI_WAVES) void gemm_qi_ws_kernel(MSe
 // The kernel's producer waves then issue nothing but global_load_lds (LDS-DMA: no VGPRs, no VALU, no LDS write
 // instructions), three steps deep in a ring of LDS buffers, and the eight consumer waves run the same MFMA / scale
 // sequence as gemm_qi_ws_kernel on the same operands: the results are bit-identical to that kernel's.
+// Measured and not kept (profiles/r03_g_prefill_planes.txt): an eight-wave workgroup in which every wave is a consumer (256
+// VGPRs; the DMAs issued through inline assembly, fragment reads a quarter step ahead of their MFMAs across the step
+// barrier): -4 %; the same with two sets of step sums and every MFMA carrying its share of the scale FMAs (packed) in its
+// shadow (sched_group_barrier): -13 %. The matrix cores are busy 0.42 of the kernel's cycles here (0.31 in
+// gemm_qi_ws_kernel); what a step still waits for is not LDS latency inside a wave.
 // Producers and consumers stay separate waves for a second reason: hipcc makes every LDS read that follows an LDS-DMA
 // issue in the same wave wait for that DMA (it cannot tell the buffers apart), which would serialise a wave that did both.
 typedef __attribute__((address_space(3))) void* lds_vptr;
@@ -789,12 +794,15 @@ struct PSegs {
   int mt_end[3];  // cumulative 256-row tile counts
   int S[3];       // K slices of each matrix
 };
-template <int TYPE, int NPX>
+// BM = 256: a workgroup takes a whole record (consumer waves 4 (rows) x 2 (tokens), 64 x 64 each); BM = 128: half a record
+// (2 x 4 waves of 64 rows x 32 tokens) -- twice the workgroups for the matrices with few row tiles (px_plan).
+template <int TYPE, int NPX, int BM>
 __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
                                                              const float* __restrict__ xsum, int tpad,
                                                              const float* __restrict__ resid, int T, int K, int mtiles,
                                                              int ntiles) {
-  constexpr int BM = PX_BM, BN = PX_BN, NI = 2, MI = 2;
+  static_assert(BM == 256 || BM == 128, "a record or half a record");
+  constexpr int BN = PX_BN, NI = BM / 128, MI = 2, HALVES = PX_BM / BM;
   constexpr bool PER16 = TYPE == TL_Q6_K;
   constexpr size_t BUF = px_buf_bytes<NPX>();
   constexpr int XPL = BN * LROW;
@@ -820,10 +828,19 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
     // ---------------- producers: LDS-DMA only ----------------
     const int pw = wave - PX_CW;
     constexpr int XI = NPX * 2;       // activation DMAs per wave and step (NPX planes x 8 sixteen-token groups over 4 waves)
-    constexpr int PER = 4 + XI + 1;   // DMAs per wave and step
-    const __bf16* wsrc = segs.q[seg] + ((size_t)mt * nk_all + kbase) * (BM * LROW) + (size_t)(pw * 4) * 512 + lane * 8;
-    const float* msrc = pw < 3 ? segs.sc[seg] + ((size_t)mt * nk_all + kbase) * PX_SC + pw * 256 + lane * 4
-                               : xsum + (size_t)kbase * tpad + n0 + (lane & 31) * 4;
+    constexpr int WI = BM / 64;       // weight DMAs per wave and step (1 KB = 16 rows each)
+    constexpr int PER = WI + XI + 1;  // DMAs per wave and step
+    const int rec = mt / HALVES, half = mt - rec * HALVES;  // the 256-row record of this tile, and which half of it
+    const __bf16* wsrc = segs.q[seg] + ((size_t)rec * nk_all + kbase) * (PX_BM * LROW) + (size_t)half * (BM * LROW) +
+                         (size_t)(pw * WI) * 512 + lane * 8;
+    // the scale words: BM = 256: waves 0..2 a KB each of sA | sB; BM = 128: wave 0 (and 2, again: every wave issues the same
+    // number of DMAs) this half's sA, wave 1 this half's sB (512 B; the upper lanes repeat it into the slack behind);
+    // wave 3: the block sums of x
+    const float* scb = segs.sc[seg] + ((size_t)rec * nk_all + kbase) * PX_SC;
+    const float* msrc = pw == 3 ? xsum + (size_t)kbase * tpad + n0 + (lane & 31) * 4
+                        : BM == 256 ? scb + pw * 256 + lane * 4
+                        : pw == 1   ? scb + 2 * PX_BM + half * BM + (lane & 31) * 4
+                                    : scb + half * (2 * BM) + lane * 4;
     const size_t mstep = pw < 3 ? (size_t)PX_SC : (size_t)tpad;
     const __bf16* xsrc[XI];
     int xdst[XI];
@@ -834,12 +851,13 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
       xsrc[j] = xp + (size_t)p * plane_stride + (size_t)(n0 + row) * K + (size_t)kbase * GB_K + chunk * 8;
       xdst[j] = (int)(PX_WBYTES + p * PX_XBYTES + i * 1024);
     }
-    const int mdst = (int)(PX_WBYTES + NPX * PX_XBYTES) + (pw < 3 ? pw * 1024 : PX_SC * 4);
+    const int mdst = (int)(PX_WBYTES + NPX * PX_XBYTES) +
+                     (pw == 3 ? PX_SC * 4 : BM == 256 ? pw * 1024 : pw == 1 ? 2 * BM * 4 : 0);
     auto issue = [&](int kk) {
       unsigned char* b = lds_raw + (size_t)(kk % PX_NB) * BUF;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_global_load_lds((glb_vptr)(wsrc + (size_t)kk * (BM * LROW) + i * 512), (lds_vptr)(b + (pw * 4 + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < WI; ++i)
+        __builtin_amdgcn_global_load_lds((glb_vptr)(wsrc + (size_t)kk * (PX_BM * LROW) + i * 512), (lds_vptr)(b + (pw * WI + i) * 1024), 16, 0, 0);
 #pragma unroll
       for (int j = 0; j < XI; ++j)
         __builtin_amdgcn_global_load_lds((glb_vptr)(xsrc[j] + (size_t)kk * GB_K), (lds_vptr)(b + xdst[j]), 16, 0, 0);
@@ -856,10 +874,11 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
     }
     return;
   }
-  // ---------------- consumers: wave = 64 tokens x 64 rows ----------------
-  const int wm = wave & 3, wn = wave >> 2;
+  // ---------------- consumers: wave = 64 rows x 32 NI tokens ----------------
+  const int wm = BM == 256 ? wave & 3 : wave & 1, wn = BM == 256 ? wave >> 2 : wave >> 1;
   const int fr = lane & 31, fh = lane >> 5;
   const int lrow0 = wm * 64 + fr;
+  const int tb = wn * (32 * NI);  // the wave's first token of the tile
   f32x16 acc[NI][MI];
 #pragma unroll
   for (int i = 0; i < NI; ++i)
@@ -884,7 +903,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
         bf16x8 a[NPX];
 #pragma unroll
         for (int p = 0; p < NPX; ++p)
-          a[p] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(wn * 64 + 32 * i + fr, k16 * 2 + fh));
+          a[p] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + lds_off(tb + 32 * i + fr, k16 * 2 + fh));
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
           const bf16x8 bq = *reinterpret_cast<const bf16x8*>(wb + lds_off(lrow0 + 32 * j, k16 * 2 + fh));
@@ -910,7 +929,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
         const float* sx = fb + PX_SC;
         f32x4 v[4];
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(sx + wn * 64 + 32 * i + 8 * g4 + 4 * fh);
+        for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(sx + tb + 32 * i + 8 * g4 + 4 * fh);
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
           const float nsb = -fb[2 * BM + lrow0 + 32 * j];
@@ -928,232 +947,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
     for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-        if (t < T) {
-          const size_t o = (size_t)t * M + m;
-          y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
-        }
-      }
-  }
-}
-
-// ---- the expanded-plane form, second kernel: every wave a consumer, fragments prefetched across the step barrier ---------
-// gemm_px_kernel's twelve waves get 168 VGPRs each and meet at one barrier per step: all eight consumers read their LDS
-// fragments at the same time, then all run their MFMAs -- the LDS pipe (160 KB of fragment reads + 44 KB of DMA writes per
-// step, ~1600 cycles at 128 B/clk) and the matrix cores (~1540 cycles) take turns. Here a workgroup is eight waves (256
-// VGPRs each), every wave issues its share of the step's DMAs itself -- through inline assembly, so that hipcc does not
-// know them and does not make the LDS reads that follow wait for them -- and the fragment reads run a quarter step ahead
-// of the MFMAs that use them, across the step barrier (which sits in the middle of a step's last quarter: "my reads of
-// this buffer have returned, my DMAs of the next step have landed"). Same operands, same order of FP operations per
-// accumulator: bit-identical to gemm_px_kernel and gemm_qi_ws_kernel.
-typedef __attribute__((address_space(3))) unsigned char* lds_bptr;
-__device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void px2_wait_and_meet() {  // this wave's LDS reads have returned, all but its last N DMAs have landed
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-}
-constexpr int PX2_THREADS = 512;
-template <int TYPE, int NPX>
-__global__ __launch_bounds__(PX2_THREADS) void gemm_px2_kernel(PSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
-                                                               const float* __restrict__ xsum, int tpad,
-                                                               const float* __restrict__ resid, int T, int K, int mtiles,
-                                                               int ntiles) {
-  constexpr int BM = PX_BM, BN = PX_BN, NI = 2, MI = 2;
-  constexpr bool PER16 = TYPE == TL_Q6_K;
-  constexpr unsigned BUF = (unsigned)px_buf_bytes<NPX>();
-  constexpr int XPL = BN * LROW;
-  constexpr int PER = 3 + NPX;  // DMAs per wave and step: 2 of the weight tile, one per activation plane, one of the scale words
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  const int total = mtiles * ntiles;
-  int tile = blockIdx.x;
-  if ((total & 7) == 0) tile = (blockIdx.x & 7) * (total >> 3) + (blockIdx.x >> 3);
-  const int nt = tile / mtiles;
-  int mt = tile - nt * mtiles;
-  const int seg = (mt >= segs.mt_end[0]) + (mt >= segs.mt_end[1]);
-  if (seg) mt -= segs.mt_end[seg - 1];
-  const int nslices = segs.S[seg];
-  if ((int)blockIdx.y >= nslices) return;  // (uniform over the workgroup, before any barrier)
-  const int M = segs.M[seg];
-  float* __restrict__ y = segs.y[seg];
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int nk_all = K / GB_K, kper = (nk_all + nslices - 1) / nslices;
-  const int kbase = (int)blockIdx.y * kper;
-  const int nk = nk_all - kbase < kper ? nk_all - kbase : kper;
-  if (nslices > 1) y += (size_t)blockIdx.y * (size_t)T * (size_t)M;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned lds0 = (unsigned)(size_t)(lds_bptr)lds_raw;
-  // ---- this wave's share of a step's DMAs ----
-  const __bf16* wsrc = segs.q[seg] + ((size_t)mt * nk_all + kbase) * (BM * LROW) + (size_t)(wave * 2) * 512 + lane * 8;
-  const int mi = wave & 3;  // (waves 4..7 repeat the scale-word DMAs of waves 0..3: same words to the same place)
-  const float* msrc = mi < 3 ? segs.sc[seg] + ((size_t)mt * nk_all + kbase) * PX_SC + mi * 256 + lane * 4
-                             : xsum + (size_t)kbase * tpad + n0 + (lane & 31) * 4;
-  const size_t mstep = mi < 3 ? (size_t)PX_SC : (size_t)tpad;
-  const unsigned mdst = (unsigned)(PX_WBYTES + NPX * PX_XBYTES) + (mi < 3 ? mi * 1024u : PX_SC * 4u);
-  const __bf16* xsrc;
-  {
-    const int row = wave * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
-    xsrc = xp + (size_t)(n0 + row) * K + (size_t)kbase * GB_K + chunk * 8;
-  }
-  auto issue = [&](int kk, unsigned b) {  // b: LDS address of the step's buffer
-    dma16(wsrc + (size_t)kk * (BM * LROW), b + (wave * 2) * 1024u);
-    dma16(wsrc + (size_t)kk * (BM * LROW) + 512, b + (wave * 2 + 1) * 1024u);
-#pragma unroll
-    for (int p = 0; p < NPX; ++p)
-      dma16(xsrc + (size_t)p * plane_stride + (size_t)kk * GB_K, b + (unsigned)(PX_WBYTES + p * PX_XBYTES) + wave * 1024u);
-    dma16(msrc + (size_t)kk * mstep, b + mdst);
-  };
-  // ---- consumer side: wave = 64 rows x 64 tokens ----
-  const int wm = wave & 3, wn = wave >> 2;
-  const int fr = lane & 31, fh = lane >> 5;
-  const int lrow0 = wm * 64 + fr;
-  const int sw = (fr >> 2) & 3;  // (row >> 2) & 3 of every row this lane reads: rows are fr + a multiple of 32
-  int aoff[NI][2], boff[MI][2];  // element offsets of this lane's fragments inside a buffer
-#pragma unroll
-  for (int k16 = 0; k16 < 2; ++k16) {
-#pragma unroll
-    for (int i = 0; i < NI; ++i) aoff[i][k16] = (wn * 64 + 32 * i + fr) * LROW + (((k16 * 2 + fh) ^ sw) << 3);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) boff[j][k16] = (lrow0 + 32 * j) * LROW + (((k16 * 2 + fh) ^ sw) << 3);
-  }
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  bf16x8 a0[NPX], a1[NPX], bq[2][MI];
-  auto load_a = [&](bf16x8* a, const unsigned char* b, int i, int k16) {
-    const __bf16* xb = reinterpret_cast<const __bf16*>(b + PX_WBYTES);
-#pragma unroll
-    for (int p = 0; p < NPX; ++p) a[p] = *reinterpret_cast<const bf16x8*>(xb + p * XPL + aoff[i][k16]);
-  };
-  auto load_b = [&](const unsigned char* b, int k16) {
-    const __bf16* wb = reinterpret_cast<const __bf16*>(b);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) bq[k16][j] = *reinterpret_cast<const bf16x8*>(wb + boff[j][k16]);
-  };
-  auto mfma_q = [&](f32x16* t, const bf16x8* a, int k16) {
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-#pragma unroll
-      for (int p = NPX - 1; p >= 0; --p) t[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[p], bq[k16][j], t[j], 0, 0, 0);  // smallest plane first
-  };
-  // prologue: three steps in flight, then the first fragments
-  issue(0, lds0);
-  if (nk > 1) issue(1, lds0 + BUF);
-  if (nk > 2) issue(2, lds0 + 2 * BUF);
-  if (nk > 2) px2_wait_and_meet<2 * PER>();
-  else if (nk > 1) px2_wait_and_meet<PER>();
-  else px2_wait_and_meet<0>();
-  load_a(a0, lds_raw, 0, 0);
-  load_b(lds_raw, 0);
-  int cur = 0;  // buffer of step kk
-  for (int kk = 0; kk < nk; ++kk) {
-    const unsigned char* cb = lds_raw + (size_t)cur * BUF;
-    const int nxt = cur == PX_NB - 1 ? 0 : cur + 1;
-    const unsigned char* nb = lds_raw + (size_t)nxt * BUF;
-    const float* fb = reinterpret_cast<const float*>(cb + PX_WBYTES + NPX * PX_XBYTES);
-    f32x16 t[MI];
-    float sa[MI][2], nsb[MI];
-    f32x4 v[4];
-    // ---- quarter 0: (tokens 0, columns 0..15) ----
-    load_a(a1, cb, 0, 1);
-    load_b(cb, 1);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      sa[j][0] = fb[2 * (lrow0 + 32 * j)];
-      sa[j][1] = fb[2 * (lrow0 + 32 * j) + 1];
-      if (TYPE == TL_Q4_K) nsb[j] = -fb[2 * BM + lrow0 + 32 * j];
-    }
-    if (TYPE == TL_Q4_K) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(fb + PX_SC + wn * 64 + 8 * g4 + 4 * fh);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) t[j] = zero;
-    mfma_q(t, a0, 0);
-    if (PER16) {
-#pragma unroll
-      for (int j = 0; j < MI; ++j) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][j][e] = fmaf(sa[j][0], t[j][e], acc[0][j][e]);
-        t[j] = zero;
-      }
-    }
-    // ---- quarter 1: (tokens 0, columns 16..31) ----
-    load_a(a0, cb, 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_q(t, a1, 1);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const float s = PER16 ? sa[j][1] : sa[j][0];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[0][j][e] = fmaf(s, t[j][e], acc[0][j][e]);
-    }
-    if (TYPE == TL_Q4_K) {
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][j][e] = fmaf(nsb[j], v[e >> 2][e & 3], acc[0][j][e]);
-    }
-    // ---- quarter 2: (tokens 1, columns 0..15) ----
-    load_a(a1, cb, 1, 1);
-    if (TYPE == TL_Q4_K) {
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) v[g4] = *reinterpret_cast<const f32x4*>(fb + PX_SC + wn * 64 + 32 + 8 * g4 + 4 * fh);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) t[j] = zero;
-    mfma_q(t, a0, 0);
-    if (PER16) {
-#pragma unroll
-      for (int j = 0; j < MI; ++j) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[1][j][e] = fmaf(sa[j][0], t[j][e], acc[1][j][e]);
-        t[j] = zero;
-      }
-    }
-    // ---- quarter 3: (tokens 1, columns 16..31); the step barrier; the next step's first fragments ----
-    if (kk + 1 < nk) {
-      // every read of this buffer has returned, the DMAs of step kk + 1 have landed (those of kk + 2 may be in flight):
-      // after the barrier this buffer takes step kk + 3
-      if (kk + 2 < nk) px2_wait_and_meet<PER>();
-      else px2_wait_and_meet<0>();
-      if (kk + 3 < nk) issue(kk + 3, lds0 + (unsigned)cur * BUF);
-      load_a(a0, nb, 0, 0);
-      load_b(nb, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    mfma_q(t, a1, 1);
-#pragma unroll
-    for (int j = 0; j < MI; ++j) {
-      const float s = PER16 ? sa[j][1] : sa[j][0];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[1][j][e] = fmaf(s, t[j][e], acc[1][j][e]);
-    }
-    if (TYPE == TL_Q4_K) {
-#pragma unroll
-      for (int j = 0; j < MI; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[1][j][e] = fmaf(nsb[j], v[e >> 2][e & 3], acc[1][j][e]);
-    }
-    cur = nxt;
-  }
-#pragma unroll
-  for (int j = 0; j < MI; ++j) {
-    const int m = m0 + lrow0 + 32 * j;
-    if (m >= M) continue;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int t = n0 + wn * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+        const int t = n0 + tb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
         if (t < T) {
           const size_t o = (size_t)t * M + m;
           y[o] = resid ? resid[o] + acc[i][j][e] : acc[i][j][e];
@@ -1746,23 +1540,31 @@ static bool px_ready(const QW* w, int n) {
     if (!px_lookup(w[i], &e)) return false;
   return true;
 }
-// K slices of an expanded-plane launch of `tiles` workgroup tiles (256 rows x 128 tokens) over nk_all 32-column steps: one
-// workgroup per CU, so the cost of a launch is (rounds of workgroups over the chip) x (steps of a workgroup + ~8 steps' worth
-// of ring fill and tile store), plus the partial tiles the consumer has to sum (TL_GEMM_PX_SLICES=0: the unpacking kernel's
-// slice counts, which make the two kernels agree bit for bit: parity runs)
-static int px_slices(int tiles, int nk_all) {
-  if (!ksplit_enabled()) return 1;
+// Row-tile size and K slices of an expanded-plane launch of n matrices over `ntiles` token tiles and nk_all 32-column steps.
+// One workgroup per CU, so the cost of a launch is (rounds of workgroups over the chip) x (steps of a workgroup + the
+// ring fill and the tile store, ~8 steps' worth), plus the partial tiles the consumer has to sum; a 128-row step costs
+// ~0.6 of a 256-row one (measured), and is taken where 256-row tiles leave CUs idle or slices short (attn_output / ffn_down /
+// q | k | v at 128 tokens). TL_GEMM_PX_SLICES=0: 256 rows and the unpacking kernel's slice counts, which make the two
+// kernels agree bit for bit (parity runs).
+struct PxPlan {
+  int bm, S;
+};
+static PxPlan px_plan(const QW* w, int n, int ntiles, int nk_all) {
   const int cus = gemm_num_cus();
-  int best = 1;
+  PxPlan best = {PX_BM, 1};
   long best_cost = -1;
-  for (int S = 1; S <= 8; ++S) {
-    const int kper = (nk_all + S - 1) / S;
-    if (S > 1 && (kper < 12 || (nk_all + kper - 1) / kper != S)) continue;  // a dozen steps per slice at least, no empty slice
-    const long rounds = ((long)tiles * S + cus - 1) / cus;
-    const long cost = rounds * (kper + 8) + (S > 1 ? 2 * S : 0);
-    if (best_cost < 0 || cost < best_cost) {
-      best_cost = cost;
-      best = S;
+  for (int bm : {256, 128}) {
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) tiles += (long)((w[i].rows + bm - 1) / bm) * ntiles;
+    for (int S = 1; S <= (ksplit_enabled() ? 8 : 1); ++S) {
+      const int kper = (nk_all + S - 1) / S;
+      if (S > 1 && (kper < 12 || (nk_all + kper - 1) / kper != S)) continue;  // a dozen steps per slice at least, no empty slice
+      const long rounds = (tiles * S + cus - 1) / cus;
+      const long cost = rounds * (bm == 256 ? 10L * kper + 80 : 6L * kper + 60) + (S > 1 ? 20L * S : 0);
+      if (best_cost < 0 || cost < best_cost) {
+        best_cost = cost;
+        best = {bm, S};
+      }
     }
   }
   return best;
@@ -1773,18 +1575,25 @@ static bool px_own_slices() {
 }
 // the expanded-plane launch of n <= 3 matrices (same format and width) with S[i] K slices each; false: not every matrix has
 // its planes (the caller takes the unpacking kernel)
+template <int TYPE, int NPX, int BM>
+int launch_gemm_px_bm(const PSegs& g, int mt, int ntiles, int smax, const __bf16* xp, size_t ps, const float* xsum, int tpad,
+                      const float* resid, int T, int K, hipStream_t s) {
+  constexpr size_t lds = PX_NB * px_buf_bytes<NPX>();
+  static_assert(lds <= 160 * 1024, "three LDS buffers per workgroup");
+  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
+  TL_TRY(tl_raise_lds_limit(gemm_px_kernel<TYPE, NPX, BM>, (int)lds, lds_raised));
+  gemm_px_kernel<TYPE, NPX, BM><<<dim3(mt * ntiles, smax), dim3(PX_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, K, mt, ntiles);
+  return 0;
+}
 template <int TYPE, int NPX>
 int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, const float* resid, int T,
-                   hipStream_t s, bool* done) {
+                   hipStream_t s, bool* done, int bm = PX_BM) {
   *done = false;
   if (!px_enabled()) return 0;
   PxEntry e[3];
   for (int i = 0; i < n; ++i)
     if (!px_lookup(w[i], &e[i])) return 0;
-  constexpr size_t lds = PX_NB * px_buf_bytes<NPX>();
-  static_assert(lds <= 160 * 1024, "three LDS buffers per workgroup");
-  static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
-  TL_TRY(tl_raise_lds_limit(gemm_px_kernel<TYPE, NPX>, (int)lds, lds_raised));
+  if (const char* f = getenv("TL_GEMM_PX_BM")) bm = atoi(f) == 128 ? 128 : PX_BM;  // (parity / A/B runs; read at every launch)
   const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
   const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + PX_BN - 1) / PX_BN;
   PSegs g = {};
@@ -1796,18 +1605,12 @@ int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const
     g.y[i] = out[k];
     g.M[i] = w[k].rows;
     g.S[i] = S[k];
-    if (i < n) mt += (w[i].rows + PX_BM - 1) / PX_BM;
+    if (i < n) mt += (w[i].rows + bm - 1) / bm;
     g.mt_end[i] = mt;
     if (S[k] > smax) smax = S[k];
   }
-  const char* v2 = getenv("TL_GEMM_PX2");  // 1: the all-consumer kernel (measured 4 % slower; A/B runs; read at every launch)
-  if (v2 && atoi(v2) != 0) {
-    static TlDeviceOnce lds_raised2;
-    TL_TRY(tl_raise_lds_limit(gemm_px2_kernel<TYPE, NPX>, (int)lds, lds_raised2));
-    gemm_px2_kernel<TYPE, NPX><<<dim3(mt * ntiles, smax), dim3(PX2_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, w[0].cols, mt, ntiles);
-  } else {
-    gemm_px_kernel<TYPE, NPX><<<dim3(mt * ntiles, smax), dim3(PX_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, w[0].cols, mt, ntiles);
-  }
+  if (bm == 128) TL_TRY((launch_gemm_px_bm<TYPE, NPX, 128>(g, mt, ntiles, smax, xp, ps, xsum, tpad, resid, T, w[0].cols, s)));
+  else TL_TRY((launch_gemm_px_bm<TYPE, NPX, 256>(g, mt, ntiles, smax, xp, ps, xsum, tpad, resid, T, w[0].cols, s)));
   TL_HIP(hipGetLastError());
   ++g_px_launches;
   *done = true;
@@ -1819,7 +1622,8 @@ template <int TYPE, int NPX, int BN, int BM>
 int launch_gemm_qi_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, int T, hipStream_t s) {
   if constexpr (BN == GB_N && BM == 128) {  // the same sums from the expanded planes, where every matrix has them
     bool done = false;
-    TL_TRY((launch_gemm_px<TYPE, NPX>(w, n, xp, ps, out, S, nullptr, T, s, &done)));
+    const int bm = px_own_slices() && px_ready(w, n) ? px_plan(w, n, (T + BN - 1) / BN, w[0].cols / GB_K).bm : PX_BM;
+    TL_TRY((launch_gemm_px<TYPE, NPX>(w, n, xp, ps, out, S, nullptr, T, s, &done, bm)));
     if (done) return 0;
   }
   constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
@@ -1852,8 +1656,13 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   const int tpad = (int)tl_gemm_padded_tokens(T);
   const int tiles = mtiles * ntiles;
   int S = qi_slices(tiles, w.cols / GB_K, T);  // split K as in launch_gemm_ws_bn
+  int px_bm = PX_BM;
   if constexpr (BN == GB_N && BM == 128) {
-    if (px_own_slices() && px_ready(&w, 1)) S = px_slices((w.rows + PX_BM - 1) / PX_BM * ntiles, w.cols / GB_K);
+    if (px_own_slices() && px_ready(&w, 1)) {
+      const PxPlan pl = px_plan(&w, 1, ntiles, w.cols / GB_K);
+      S = pl.S;
+      px_bm = pl.bm;
+    }
   }
   float* part = nullptr;
   bool deferred = false;
@@ -1861,7 +1670,7 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   if constexpr (BN == GB_N && BM == 128) {  // the same sums (same K slices) from the expanded planes, if this matrix has them
     bool done = false;
     float* o = S == 1 ? y : part;
-    TL_TRY((launch_gemm_px<TYPE, NPX>(&w, 1, xp, ps, &o, &S, S == 1 ? resid : nullptr, T, s, &done)));
+    TL_TRY((launch_gemm_px<TYPE, NPX>(&w, 1, xp, ps, &o, &S, S == 1 ? resid : nullptr, T, s, &done, px_bm)));
     if (done) {
       if (S > 1) ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
       TL_HIP(hipGetLastError());
@@ -2231,11 +2040,8 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
     S[0] = S[1] = S[2] = qd_slices(tiles, w[0].cols / 64, gemm_num_cus());
   } else {
     for (int i = 0; i < n; ++i) S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K, T);
-    if (BN == GB_N && px_own_slices() && px_ready(w, n)) {  // the expanded-plane kernel: one slice count from the launch's tiles
-      int tiles = 0;
-      for (int i = 0; i < n; ++i) tiles += (w[i].rows + PX_BM - 1) / PX_BM * ntiles;
-      S[0] = S[1] = S[2] = px_slices(tiles, w[0].cols / GB_K);
-    }
+    if (BN == GB_N && px_own_slices() && px_ready(w, n))  // the expanded-plane kernel: one slice count from the launch's tiles
+      S[0] = S[1] = S[2] = px_plan(w, n, ntiles, w[0].cols / GB_K).S;
   }
   TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w[0].cols, "tl_launch_gemm_q_multi: activation planes too small");
   float* out[3] = {nullptr, nullptr, nullptr};

@@ -19,7 +19,7 @@ for r in csv.DictReader(open(f)):
     c = a.setdefault(r["Counter_Name"], [0, 0.0]); c[0] += 1; c[1] += float(r["Counter_Value"])
 out = []
 for k, a in agg.items():
-    if "gemm_q" not in k and "attn_prefill" not in k: continue
+    if "gemm_q" not in k and "gemm_px" not in k and "attn_prefill" not in k: continue
     row = {"kernel": k[:100]}
     for name, (n, v) in a.items():
         row[name] = v / n; row["launches"] = n

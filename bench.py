@@ -355,6 +355,9 @@ def main():
         "gemv_kernels": kern,
         "eager_step_us": {k: round(v[0] * 1e3, 2) for k, v in prof.items()},
         "load_s": round(t_load, 1),
+        # the expanded copy of the matrices kept for the batched legs below (tl_qweight_expand; 0: none): never read by
+        # the timed decode step, whose bytes are the quantized planes counted above
+        "prefill_planes_bytes_per_gpu": int(model.prefill_planes_bytes()),
     }
     if world > 1:  # the multi-rank line describes itself at the top level (the driver keeps only this line)
         ar = kern.get("tp_all_reduce", {})

@@ -208,6 +208,10 @@ int tl_model_set_prefill(tl_model* m, int terms, int min_batch);
 int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev_out);
 /* algorithmic bytes one decode step at position pos must move on this rank (SURVEY §8d B_tok) */
 int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, double* kv_bytes);
+/* device bytes of the expanded prefill planes that tl_model_finalize keeps for this model's matrices (tl_qweight_expand;
+ * 0: none -- switched off, or not affordable on this device). They serve the batched paths only: a decode step never
+ * reads them. */
+int tl_model_prefill_planes_bytes(const tl_model* m, size_t* bytes_out);
 /* Multi-sequence decode (generate_batch api.cpp:836-1142; batch_prefill_parallel :1144, batch_generation_parallel :1423;
  * forward_cpu_batch_generation model.cpp:1158-1523 / forward_device_batch_generation :1863-2114): up to max_batch
  * sequences share the weights of every step -- the projections of the B tokens are skinny GEMMs on the matrix cores, the

@@ -80,6 +80,7 @@ SIGNATURES = {
     "tl_gemm_set_terms": [C.c_int],
     "tl_model_device_ptr": [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)],
     "tl_model_bytes_per_token": [_vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)],
+    "tl_model_prefill_planes_bytes": [_vp, C.POINTER(_sz)],
     "tl_tp_unique_id": [_vp],
     "tl_tp_local_group_prefill": [_vp, C.c_int, _vp, C.c_int, C.c_int, _vp],
     "tl_model_graph_captured": [_vp, _vp],

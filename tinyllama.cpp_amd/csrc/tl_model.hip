@@ -1942,6 +1942,12 @@ extern "C" int tl_model_device_ptr(tl_model* m, int which, int layer, void** dev
   return 0;
 }
 
+extern "C" int tl_model_prefill_planes_bytes(const tl_model* m, size_t* bytes_out) {
+  TL_REQUIRE(m && m->finalized && bytes_out, "tl_model_prefill_planes_bytes: bad argument");
+  *bytes_out = m->expanded_bytes;
+  return 0;
+}
+
 extern "C" int tl_model_bytes_per_token(const tl_model* m, int pos, double* weight_bytes, double* kv_bytes) {
   TL_REQUIRE(m && m->finalized, "tl_model_bytes_per_token: model not finalized");
   if (weight_bytes) *weight_bytes = m->weight_bytes;

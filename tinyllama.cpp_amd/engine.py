@@ -416,6 +416,12 @@ class Model:
         check(lib().tl_model_bytes_per_token(self.h, int(pos), C.byref(w), C.byref(kv)), "tl_model_bytes_per_token")
         return w.value, kv.value
 
+    def prefill_planes_bytes(self):
+        """Device bytes of the expanded prefill planes kept for this model (0: none), tl_model_prefill_planes_bytes."""
+        n = C.c_size_t()
+        check(lib().tl_model_prefill_planes_bytes(self.h, C.byref(n)), "tl_model_prefill_planes_bytes")
+        return n.value
+
     def free(self):
         if self.h:
             lib().tl_model_free(self.h)

@@ -796,6 +796,22 @@ struct PSegs {
 };
 // BM = 256: a workgroup takes a whole record (consumer waves 4 (rows) x 2 (tokens), 64 x 64 each); BM = 128: half a record
 // (2 x 4 waves of 64 rows x 32 tokens) -- twice the workgroups for the matrices with few row tiles (px_plan).
+#ifdef TL_PX_STAMP
+// diagnostic build only (make EXTRA=-DTL_PX_STAMP; tools/px_stamps.py): shader-clock stamps of workgroup (0, 0), lane 0 of
+// every wave, for the first PX_STAMP_STEPS steps: consumers [0] past the step barrier, [1] / [3] the first / second token
+// half's MFMAs issued, [2] / [4] its sums folded, [7] about to meet; producers [0] past the barrier, [1] DMAs of step kk + 2
+// issued, [2] step kk + 1 landed (about to meet). The stamps cost time themselves (a stamped step is ~1.5x a plain one).
+constexpr int PX_STAMP_STEPS = 48;
+__device__ unsigned long long px_stamps[PX_PW + PX_CW][PX_STAMP_STEPS][8];
+#define PX_STAMP(k, slot)                                                                                       \
+  do {                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (k) < PX_STAMP_STEPS) px_stamps[wave][(k)][(slot)] = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0);                                                                          \
+  } while (0)
+#else
+#define PX_STAMP(k, slot) do { } while (0)
+#endif
 template <int TYPE, int NPX, int BM>
 __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
                                                              const float* __restrict__ xsum, int tpad,
@@ -868,9 +884,13 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
     for (int kk = 0; kk < nk; ++kk) {
       // step kk has landed (the DMAs of step kk + 1 may still be in flight); meet the consumers, who are through with step
       // kk - 1: its buffer takes step kk + 2
-      if (kk + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(PER) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (kk + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PX_STAMP(kk, 2);
+      asm volatile("s_barrier" ::: "memory");
+      PX_STAMP(kk, 0);
       if (kk + 2 < nk) issue(kk + 2);
+      PX_STAMP(kk, 1);
     }
     return;
   }
@@ -888,7 +908,9 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int kk = 0; kk < nk; ++kk) {
+    PX_STAMP(kk, 7);
     __syncthreads();
+    PX_STAMP(kk, 0);
     const unsigned char* b = lds_raw + (size_t)(kk % PX_NB) * BUF;
     const __bf16* wb = reinterpret_cast<const __bf16*>(b);
     const __bf16* xb = reinterpret_cast<const __bf16*>(b + PX_WBYTES);
@@ -917,6 +939,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
           }
         }
       }
+      PX_STAMP(kk, 1 + 2 * i);
       if (!PER16) {
 #pragma unroll
         for (int j = 0; j < MI; ++j) {
@@ -937,6 +960,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
           for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf(nsb, v[e >> 2][e & 3], acc[i][j][e]);
         }
       }
+      PX_STAMP(kk, 2 + 2 * i);
     }
   }
 #pragma unroll
@@ -2111,6 +2135,16 @@ extern "C" int tl_qweight_expand(tl_qweight* w, size_t* expanded_bytes, void* st
   return 0;
 }
 
+#ifdef TL_PX_STAMP
+extern "C" int tl_debug_px_stamps(unsigned long long* host_out, int clear) {
+  if (host_out) TL_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(px_stamps), sizeof(px_stamps)));
+  if (clear) {
+    static unsigned long long zeros[PX_PW + PX_CW][PX_STAMP_STEPS][8];
+    TL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(px_stamps), zeros, sizeof(zeros)));
+  }
+  return 0;
+}
+#endif
 // Diagnostic hook (include/tlhip_debug.h): launches of the expanded-plane kernel so far in this process
 extern "C" int tl_debug_gemm_px_launches(long long* count_out) {
   TL_REQUIRE(count_out, "tl_debug_gemm_px_launches: null argument");

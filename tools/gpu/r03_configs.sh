@@ -10,7 +10,7 @@ A="--no-cpu-baseline --no-batch-leg --steps 128 --warmup 16"
 timeout -k 10 300 python bench.py --workload tinyllama-1.1b --mix q8_0 $A > $O/tinyllama-1.1b_q8_0.json 2> $O/tinyllama-1.1b_q8_0.err || exit 1
 timeout -k 10 300 python bench.py --workload tinyllama-1.1b --mix q4_k_m $A > $O/tinyllama-1.1b_q4_k_m.json 2> $O/tinyllama-1.1b_q4_k_m.err || exit 1
 timeout -k 10 300 python bench.py --workload llama-3.2-3b $A > $O/llama-3.2-3b_q6_k.json 2> $O/llama-3.2-3b_q6_k.err || exit 1
-timeout -k 10 300 python bench.py --workload llama-3-8b $A --no-prefill-leg > $O/8b_short.json 2> $O/8b_short.err || exit 1
+timeout -k 10 300 python bench.py --workload llama-3-8b --no-cpu-baseline --steps 128 --warmup 16 > $O/8b_short.json 2> $O/8b_short.err || exit 1
 timeout -k 10 300 python bench.py --workload llama-3-8b --max-pos 8192 --prompt-len 2000 $A --no-prefill-leg > $O/8b_ctx2k.json 2> $O/8b_ctx2k.err || exit 1
 timeout -k 10 300 python bench.py --workload llama-3-8b --max-pos 8192 --prompt-len 8000 $A --no-prefill-leg > $O/8b_ctx8k.json 2> $O/8b_ctx8k.err || exit 1
 if [ "${SKIP_70B:-0}" != "1" ]; then

@@ -133,7 +133,8 @@ def test_few_tokens_take_the_multi_vector_gemv(E, pkg, oracle, name, rows, cols,
 @pytest.mark.parametrize("name,rows,cols,T", [
     ("q4_k", 512, 1024, 65), ("q4_k", 333, 512, 130), ("q4_k", 4096, 4096, 512), ("q4_k", 1024, 14336, 128),
     ("q6_k", 256, 1024, 200), ("q6_k", 4100, 4096, 257), ("q8_0", 192, 512, 129), ("q8_0", 2048, 2048, 384),
-    ("q8_k", 128, 768, 140), ("q6_k", 1000, 256, 100)])
+    ("q8_k", 128, 768, 140), ("q6_k", 1000, 256, 100), ("q4_k", 4096, 4096, 64), ("q4_k", 700, 14336, 40),
+    ("q6_k", 1024, 4096, 50), ("q8_0", 300, 512, 33)])
 def test_expanded_plane_gemm_is_bit_identical(E, pkg, oracle, monkeypatch, name, rows, cols, T):
     """tl_qweight_expand: the batched GEMM fed by LDS-DMA from the resident bf16 integer plane + scale words
     (gemm_px_kernel, 256-row tiles, producers that only issue DMAs) forms exactly the sums of the kernel that unpacks the

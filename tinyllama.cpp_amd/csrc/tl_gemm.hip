@@ -812,16 +812,18 @@ __device__ unsigned long long px_stamps[PX_PW + PX_CW][PX_STAMP_STEPS][8];
 #else
 #define PX_STAMP(k, slot) do { } while (0)
 #endif
-template <int TYPE, int NPX, int BM>
+// BN = 64 (with BM = 256 only): 64-token tiles for launches of 33..64 tokens (4 x 2 waves of 64 rows x 32 tokens).
+template <int TYPE, int NPX, int BM, int BN = PX_BN>
 __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const __bf16* __restrict__ xp, size_t plane_stride,
                                                              const float* __restrict__ xsum, int tpad,
                                                              const float* __restrict__ resid, int T, int K, int mtiles,
                                                              int ntiles) {
   static_assert(BM == 256 || BM == 128, "a record or half a record");
-  constexpr int BN = PX_BN, NI = BM / 128, MI = 2, HALVES = PX_BM / BM;
+  static_assert(BN == 128 || (BN == 64 && BM == 256), "64-token tiles with whole records only");
+  constexpr int NI = BM == 256 ? BN / 64 : 1, MI = 2, HALVES = PX_BM / BM;
   constexpr bool PER16 = TYPE == TL_Q6_K;
   constexpr size_t BUF = px_buf_bytes<NPX>();
-  constexpr int XPL = BN * LROW;
+  constexpr int XPL = PX_BN * LROW;  // (the LDS image keeps room for 128 tokens per plane)
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int total = mtiles * ntiles;
   int tile = blockIdx.x;
@@ -843,7 +845,8 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
   if (wave >= PX_CW) {
     // ---------------- producers: LDS-DMA only ----------------
     const int pw = wave - PX_CW;
-    constexpr int XI = NPX * 2;       // activation DMAs per wave and step (NPX planes x 8 sixteen-token groups over 4 waves)
+    constexpr int XG = BN / 16;       // sixteen-token groups of a plane
+    constexpr int XI = NPX * XG / 4;  // activation DMAs per wave and step (NPX planes x XG groups over 4 waves)
     constexpr int WI = BM / 64;       // weight DMAs per wave and step (1 KB = 16 rows each)
     constexpr int PER = WI + XI + 1;  // DMAs per wave and step
     const int rec = mt / HALVES, half = mt - rec * HALVES;  // the 256-row record of this tile, and which half of it
@@ -853,7 +856,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
     // number of DMAs) this half's sA, wave 1 this half's sB (512 B; the upper lanes repeat it into the slack behind);
     // wave 3: the block sums of x
     const float* scb = segs.sc[seg] + ((size_t)rec * nk_all + kbase) * PX_SC;
-    const float* msrc = pw == 3 ? xsum + (size_t)kbase * tpad + n0 + (lane & 31) * 4
+    const float* msrc = pw == 3 ? xsum + (size_t)kbase * tpad + n0 + (lane & (BN / 4 - 1)) * 4  // (BN block sums; the other lanes repeat them)
                         : BM == 256 ? scb + pw * 256 + lane * 4
                         : pw == 1   ? scb + 2 * PX_BM + half * BM + (lane & 31) * 4
                                     : scb + half * (2 * BM) + lane * 4;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(PX_THREADS) void gemm_px_kernel(PSegs segs, const _
     int xdst[XI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
-      const int idx = pw * XI + j, p = idx >> 3, i = idx & 7;
+      const int idx = pw * XI + j, p = idx / XG, i = idx % XG;
       const int row = i * 16 + (lane >> 2), chunk = (lane & 3) ^ ((row >> 2) & 3);
       xsrc[j] = xp + (size_t)p * plane_stride + (size_t)(n0 + row) * K + (size_t)kbase * GB_K + chunk * 8;
       xdst[j] = (int)(PX_WBYTES + p * PX_XBYTES + i * 1024);
@@ -1573,18 +1576,19 @@ static bool px_ready(const QW* w, int n) {
 struct PxPlan {
   int bm, S;
 };
-static PxPlan px_plan(const QW* w, int n, int ntiles, int nk_all) {
+static PxPlan px_plan(const QW* w, int n, int ntiles, int nk_all, int bn = PX_BN) {
   const int cus = gemm_num_cus();
   PxPlan best = {PX_BM, 1};
   long best_cost = -1;
   for (int bm : {256, 128}) {
+    if (bn == 64 && bm == 128) continue;  // (64-token tiles take whole records)
     long tiles = 0;
     for (int i = 0; i < n; ++i) tiles += (long)((w[i].rows + bm - 1) / bm) * ntiles;
     for (int S = 1; S <= (ksplit_enabled() ? 8 : 1); ++S) {
       const int kper = (nk_all + S - 1) / S;
       if (S > 1 && (kper < 12 || (nk_all + kper - 1) / kper != S)) continue;  // a dozen steps per slice at least, no empty slice
       const long rounds = (tiles * S + cus - 1) / cus;
-      const long cost = rounds * (bm == 256 ? 10L * kper + 80 : 6L * kper + 60) + (S > 1 ? 20L * S : 0);
+      const long cost = rounds * (bm == 256 && bn == PX_BN ? 10L * kper + 80 : 6L * kper + 60) + (S > 1 ? 20L * S : 0);
       if (best_cost < 0 || cost < best_cost) {
         best_cost = cost;
         best = {bm, S};
@@ -1599,19 +1603,19 @@ static bool px_own_slices() {
 }
 // the expanded-plane launch of n <= 3 matrices (same format and width) with S[i] K slices each; false: not every matrix has
 // its planes (the caller takes the unpacking kernel)
-template <int TYPE, int NPX, int BM>
+template <int TYPE, int NPX, int BM, int BN = PX_BN>
 int launch_gemm_px_bm(const PSegs& g, int mt, int ntiles, int smax, const __bf16* xp, size_t ps, const float* xsum, int tpad,
                       const float* resid, int T, int K, hipStream_t s) {
   constexpr size_t lds = PX_NB * px_buf_bytes<NPX>();
   static_assert(lds <= 160 * 1024, "three LDS buffers per workgroup");
   static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
-  TL_TRY(tl_raise_lds_limit(gemm_px_kernel<TYPE, NPX, BM>, (int)lds, lds_raised));
-  gemm_px_kernel<TYPE, NPX, BM><<<dim3(mt * ntiles, smax), dim3(PX_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, K, mt, ntiles);
+  TL_TRY(tl_raise_lds_limit(gemm_px_kernel<TYPE, NPX, BM, BN>, (int)lds, lds_raised));
+  gemm_px_kernel<TYPE, NPX, BM, BN><<<dim3(mt * ntiles, smax), dim3(PX_THREADS), lds, s>>>(g, xp, ps, xsum, tpad, resid, T, K, mt, ntiles);
   return 0;
 }
 template <int TYPE, int NPX>
 int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, const float* resid, int T,
-                   hipStream_t s, bool* done, int bm = PX_BM) {
+                   hipStream_t s, bool* done, int bm = PX_BM, int bn = PX_BN) {
   *done = false;
   if (!px_enabled()) return 0;
   PxEntry e[3];
@@ -1619,7 +1623,8 @@ int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const
     if (!px_lookup(w[i], &e[i])) return 0;
   if (const char* f = getenv("TL_GEMM_PX_BM")) bm = atoi(f) == 128 ? 128 : PX_BM;  // (parity / A/B runs; read at every launch)
   const float* xsum = reinterpret_cast<const float*>(xp + 3 * ps);
-  const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + PX_BN - 1) / PX_BN;
+  if (bn == 64) bm = PX_BM;
+  const int tpad = (int)tl_gemm_padded_tokens(T), ntiles = (T + bn - 1) / bn;
   PSegs g = {};
   int mt = 0, smax = 1;
   for (int i = 0; i < 3; ++i) {
@@ -1633,7 +1638,8 @@ int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const
     g.mt_end[i] = mt;
     if (S[k] > smax) smax = S[k];
   }
-  if (bm == 128) TL_TRY((launch_gemm_px_bm<TYPE, NPX, 128>(g, mt, ntiles, smax, xp, ps, xsum, tpad, resid, T, w[0].cols, s)));
+  if (bn == 64) TL_TRY((launch_gemm_px_bm<TYPE, NPX, 256, 64>(g, mt, ntiles, smax, xp, ps, xsum, tpad, resid, T, w[0].cols, s)));
+  else if (bm == 128) TL_TRY((launch_gemm_px_bm<TYPE, NPX, 128>(g, mt, ntiles, smax, xp, ps, xsum, tpad, resid, T, w[0].cols, s)));
   else TL_TRY((launch_gemm_px_bm<TYPE, NPX, 256>(g, mt, ntiles, smax, xp, ps, xsum, tpad, resid, T, w[0].cols, s)));
   TL_HIP(hipGetLastError());
   ++g_px_launches;
@@ -1644,10 +1650,10 @@ int launch_gemm_px(const QW* w, int n, const __bf16* xp, size_t ps, float* const
 // n matrices in one launch (gemm_qi_ws_kernel NSEG = 3); S[i] slices for matrix i, outputs / partial tiles in out[i]
 template <int TYPE, int NPX, int BN, int BM>
 int launch_gemm_qi_multi(const QW* w, int n, const __bf16* xp, size_t ps, float* const* out, const int* S, int T, hipStream_t s) {
-  if constexpr (BN == GB_N && BM == 128) {  // the same sums from the expanded planes, where every matrix has them
+  if constexpr (BM == 128) {  // the same sums from the expanded planes, where every matrix has them
     bool done = false;
-    const int bm = px_own_slices() && px_ready(w, n) ? px_plan(w, n, (T + BN - 1) / BN, w[0].cols / GB_K).bm : PX_BM;
-    TL_TRY((launch_gemm_px<TYPE, NPX>(w, n, xp, ps, out, S, nullptr, T, s, &done, bm)));
+    const int bm = px_own_slices() && px_ready(w, n) ? px_plan(w, n, (T + BN - 1) / BN, w[0].cols / GB_K, BN).bm : PX_BM;
+    TL_TRY((launch_gemm_px<TYPE, NPX>(w, n, xp, ps, out, S, nullptr, T, s, &done, bm, BN)));
     if (done) return 0;
   }
   constexpr size_t lds = gemm_qi_lds_bytes<NPX, BN, BM>();
@@ -1681,9 +1687,9 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   const int tiles = mtiles * ntiles;
   int S = qi_slices(tiles, w.cols / GB_K, T);  // split K as in launch_gemm_ws_bn
   int px_bm = PX_BM;
-  if constexpr (BN == GB_N && BM == 128) {
+  if constexpr (BM == 128) {
     if (px_own_slices() && px_ready(&w, 1)) {
-      const PxPlan pl = px_plan(&w, 1, ntiles, w.cols / GB_K);
+      const PxPlan pl = px_plan(&w, 1, ntiles, w.cols / GB_K, BN);
       S = pl.S;
       px_bm = pl.bm;
     }
@@ -1691,10 +1697,10 @@ int launch_gemm_qi_bn(const QW& w, const __bf16* xp, size_t ps, float* y, const 
   float* part = nullptr;
   bool deferred = false;
   TL_TRY(ksplit_workspace(s, T, w.rows, &S, &part, &deferred));
-  if constexpr (BN == GB_N && BM == 128) {  // the same sums (same K slices) from the expanded planes, if this matrix has them
+  if constexpr (BM == 128) {  // the same sums (same K slices) from the expanded planes, if this matrix has them
     bool done = false;
     float* o = S == 1 ? y : part;
-    TL_TRY((launch_gemm_px<TYPE, NPX>(&w, 1, xp, ps, &o, &S, S == 1 ? resid : nullptr, T, s, &done, px_bm)));
+    TL_TRY((launch_gemm_px<TYPE, NPX>(&w, 1, xp, ps, &o, &S, S == 1 ? resid : nullptr, T, s, &done, px_bm, BN)));
     if (done) {
       if (S > 1) ksplit_finish(part, S, (size_t)T * w.rows, resid, y, deferred, s);
       TL_HIP(hipGetLastError());
@@ -2064,8 +2070,8 @@ int tl_launch_gemm_q_multi(const QW* w, int n, const void* planes, size_t plane_
     S[0] = S[1] = S[2] = qd_slices(tiles, w[0].cols / 64, gemm_num_cus());
   } else {
     for (int i = 0; i < n; ++i) S[i] = qi_slices((w[i].rows + 127) / 128 * ntiles, w[i].cols / GB_K, T);
-    if (BN == GB_N && px_own_slices() && px_ready(w, n))  // the expanded-plane kernel: one slice count from the launch's tiles
-      S[0] = S[1] = S[2] = px_plan(w, n, ntiles, w[0].cols / GB_K).S;
+    if (px_own_slices() && px_ready(w, n))  // the expanded-plane kernel: one slice count from the launch's tiles
+      S[0] = S[1] = S[2] = px_plan(w, n, ntiles, w[0].cols / GB_K, BN).S;
   }
   TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)w[0].cols, "tl_launch_gemm_q_multi: activation planes too small");
   float* out[3] = {nullptr, nullptr, nullptr};

@@ -6,16 +6,23 @@
 // start_pos + i) attends positions 0..start_pos+i of its kv head's cache rows; scores = (q . k) * scale, softmax
 // with max-subtraction and 1/(sum + 1e-9), out = sum p v.
 //
-// Shape: one workgroup of PF_NW waves per (32-query tile, head); the key tiles of 32 positions are dealt round-robin to the
-// waves, each walks its tiles with an online softmax of its own, and the waves' (max, sum, O) are merged through LDS in
-// wave order at the end (deterministic).
+// Shape: one workgroup of PF_NW = 8 waves per (head, PAIR of 32-query tiles p and ntq - 1 - p): a query tile's work grows
+// with its position (causal), a pair is the same work for every p, and every XCD gets whole heads (see the kernel). Per
+// query tile the key tiles of 32 positions are dealt round-robin to the waves, each walks its tiles with an online softmax
+// of its own, and the waves' (max, sum, O) are merged through LDS slots in wave order (deterministic).
 //   S^T[pos][q] = K Q^T : A = K tile, B = Q^T. The summation index d is permuted so that lane half h owns
-//     d in [HD/2*h, HD/2*(h+1)): a lane's K operand is then ONE contiguous half row of the cache (16-B loads straight
-//     from global memory, no LDS), and its Q operand a half row kept in registers for the whole kernel.
+//     d = 8 i + 4 h + (0..3): a lane's K operand is its own cache row, 16 bytes per load straight from global memory (no
+//     LDS; the two halves share 32-byte pieces), asked for one tile AHEAD into the registers the previous products have
+//     just read, so the round trip runs under that tile's softmax and P V. The Q operand is read from the query tile in
+//     LDS (with Q in registers too there is no room for the prefetch at two waves per SIMD).
 //   The result has the query on the lane and 16 positions in registers: row max / sum are in-register reductions plus
 //     one exchange between the lane halves.
 //   O[q][d] = P V : the S^T accumulator registers ARE the A operand of the second product (the 32x32 result layout
 //     puts the summed-over position index where the next MFMA's k index lives), V rows are read 128 B per half wave.
+// Round 3 (profiles/r03_k_prefill_attention.txt): 88 -> 47 us per layer at 512 tokens (8B shape). What the first form lost:
+// 296 registers (one wave per SIMD, nothing to overlap a wave's load round trips with), a (tile, head) grid that gave XCD 0
+// 2.4 x the work of XCD 7, two rounds of unequal workgroups, K loads exposed in front of every tile, a serial five-barrier
+// merge with four exps per output element.
 #include <math.h>
 
 #include "tl_internal.h"
@@ -132,10 +139,10 @@ __global__ __launch_bounds__(64 * PF_NW) void attn_prefill_mfma_kernel(const flo
   float kreg[HH];
   auto load_k = [&](int tile) __attribute__((always_inline)) {
     const int krow = tile * 32 + r < len ? tile * 32 + r : len - 1;
-    const float* kp = kc + (size_t)krow * kv_dim + (size_t)kvh * HD + HH * h;
+    const float* kp = kc + (size_t)krow * kv_dim + (size_t)kvh * HD + 4 * h;
 #pragma unroll
     for (int i = 0; i < HH / 4; ++i) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(kp + 4 * i);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(kp + 8 * i);
       kreg[4 * i] = v[0]; kreg[4 * i + 1] = v[1]; kreg[4 * i + 2] = v[2]; kreg[4 * i + 3] = v[3];
     }
   };
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(64 * PF_NW) void attn_prefill_mfma_kernel(const flo
     store_q(tA, 64 * tA.nact, tmp);
   }
   __syncthreads();
-  const float* qrow_s = sm_q + r * (HD + 4) + HH * h;  // this lane's half row of the query tile
+  const float* qrow_s = sm_q + r * (HD + 4) + 4 * h;  // this lane's share of its query row (d = 8 i + 4 h + 0..3)
 
   for (int ph = 0; ph < 2; ++ph) {  // the late (heavy) tile of the pair, then the early one
     const PfTile t = ph == 0 ? tA : tB;
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(64 * PF_NW) void attn_prefill_mfma_kernel(const flo
       for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
       for (int i4 = 0; i4 < HH / 4; ++i4) {
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow_s + 4 * i4);
+        const f32x4 qv = *reinterpret_cast<const f32x4*>(qrow_s + 8 * i4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[4 * i4 + c], qv[c], s, 0, 0, 0);
       }

@@ -212,7 +212,11 @@ def test_gemm_edge_scales(E, pkg, oracle):
 
 
 @pytest.mark.parametrize("nh,nkv,hd,T,start", [(4, 2, 64, 33, 0), (8, 2, 64, 100, 57), (32, 8, 128, 70, 0),
-                                               (16, 4, 128, 45, 200), (8, 8, 128, 1, 31)])
+                                               (16, 4, 128, 45, 200), (8, 8, 128, 1, 31),
+                                               # pairs of query tiles: an odd tile count (the middle tile alone), heads not
+                                               # a multiple of 8, several key tiles per wave (the K prefetch), the bench shape
+                                               (8, 2, 128, 160, 0), (12, 4, 128, 300, 100), (8, 2, 64, 257, 300),
+                                               (32, 8, 128, 512, 0)])
 def test_prefill_attention_vs_oracle(E, oracle, nh, nkv, hd, T, start):
     from tinyllama_cpp_amd.capi import lib, check
     rng = np.random.default_rng(nh * 100 + T)

@@ -116,8 +116,10 @@ __device__ __forceinline__ float batch_row_sum16(float v) {
 template <int HD, int G>
 __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a) {
   constexpr int NW = 4, LP = 16, NV = HD / 64, PP = 64 / LP, U = 8 / NV, RECL = HD + 4;
-  __shared__ __attribute__((aligned(16))) float part[NW * G * RECL];
-  __shared__ float red[16];
+  constexpr int NR = NW * PP;  // row groups per workgroup (= one DPP row of lanes in the weights phase)
+  static_assert(NR == 16, "the weights of a head's row groups are reduced inside one DPP row");
+  __shared__ __attribute__((aligned(16))) float part[NR * G * RECL];
+  __shared__ float red[16], wts[G * NR];
   __shared__ __attribute__((aligned(16))) float outbuf[G * HD];
   const int kvh = blockIdx.x, tok = blockIdx.y;
   const int head0 = (kvh * gridDim.z + blockIdx.z) * G;
@@ -238,55 +240,52 @@ __global__ __launch_bounds__(256) void attn_batch_decode_kernel(BatchAttnArgs a)
       }
     }
   }
-  // fold the PP lane groups of a wave (shuffles), then the waves (LDS)
+  // every row group's state -> an LDS record (folding the four groups of a wave in registers first is 2 x 10 LDS-path
+  // shuffles per head and lane, and four exps per output element on top: as in tl_attn_body.h)
+  const int rg = wave * PP + sub;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
+    float* rec = part + (size_t)(rg * G + g) * RECL;
 #pragma unroll
-    for (int o = 32; o >= LP; o >>= 1) {
-      const float mo = __shfl_xor(m[g], o);
-      const float mn = fmaxf(m[g], mo);
-      const float c = exp_diff(m[g], mn), co = exp_diff(mo, mn);
-      l[g] = l[g] * c + __shfl_xor(l[g], o) * co;
-#pragma unroll
-      for (int v = 0; v < NV; ++v)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[g][v][e] = acc[g][v][e] * c + __shfl_xor(acc[g][v][e], o) * co;
-      m[g] = mn;
-    }
-    if (sub == 0) {
-      float* rec = part + (size_t)(wave * G + g) * RECL;
-#pragma unroll
-      for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(rec + 64 * v + 4 * ln) = acc[g][v];
-      if (ln == 0) {
-        rec[HD] = m[g];
-        rec[HD + 1] = l[g];
-      }
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(rec + 64 * v + 4 * ln) = acc[g][v];
+    if (ln == 0) {
+      rec[HD] = m[g];
+      rec[HD + 1] = l[g];
     }
   }
   __syncthreads();
-  if (tid < G) {
-    float M = -INFINITY;
-    for (int w = 0; w < NW; ++w) M = fmaxf(M, part[(size_t)(w * G + tid) * RECL + HD]);
-    float L = 0.f;
-    for (int w = 0; w < NW; ++w) {
-      const float* rec = part + (size_t)(w * G + tid) * RECL;
-      L += rec[HD + 1] * exp_diff(rec[HD], M);
-    }
-    red[tid] = M;
-    red[8 + tid] = 1.0f / (L + 1e-9f);  // utils.cpp:692
+  if (tid < G * NR) {  // lane 16 g + r: the weight exp(m_r - M) of row group r of head g, once; 1 / (L + 1e-9)
+    const int g = tid / NR, r = tid % NR;
+    const float* rec = part + (size_t)(r * G + g) * RECL;
+    const float mr = rec[HD];
+    auto dmax = [](float v, auto ctrl_c) {
+      constexpr int CTRL = decltype(ctrl_c)::value;
+      const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+      return fmaxf(v, __builtin_bit_cast(float, t));
+    };
+    float M = dmax(mr, std::integral_constant<int, 0xB1>{});
+    M = dmax(M, std::integral_constant<int, 0x4E>{});
+    M = dmax(M, std::integral_constant<int, 0x141>{});
+    M = dmax(M, std::integral_constant<int, 0x140>{});
+    const float w = exp_diff(mr, M);  // (0 for a row group without rows)
+    const float L = batch_row_sum16(rec[HD + 1] * w);
+    wts[tid] = w;
+    if (r == 0) red[8 + g] = 1.0f / (L + 1e-9f);  // utils.cpp:692
   }
   __syncthreads();
-  for (int i = tid; i < G * HD; i += 256) {
-    const int g = i / HD, d = i % HD;
-    const float M = red[g];
-    float o = 0.f;
+  for (int i = tid; i < G * (HD / 4); i += 256) {
+    const int g = i / (HD / 4), c4 = i % (HD / 4);
+    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const float* rec = part + (size_t)(w * G + g) * RECL;
-      o += rec[d] * exp_diff(rec[HD], M);
+    for (int r = 0; r < NR; ++r) {  // row-group order
+      const f32x4 x = *reinterpret_cast<const f32x4*>(part + (size_t)(r * G + g) * RECL + 4 * c4);
+      const float w = wts[g * NR + r];
+      o[0] = fmaf(x[0], w, o[0]); o[1] = fmaf(x[1], w, o[1]); o[2] = fmaf(x[2], w, o[2]); o[3] = fmaf(x[3], w, o[3]);
     }
-    if (a.planes) outbuf[i] = o * red[8 + g];
-    else a.out[((size_t)tok * a.nh + head0 + g) * HD + d] = o * red[8 + g];
+    const float inv = red[8 + g];
+    o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+    if (a.planes) *reinterpret_cast<f32x4*>(outbuf + g * HD + 4 * c4) = o;
+    else *reinterpret_cast<f32x4*>(a.out + ((size_t)tok * a.nh + head0 + g) * HD + 4 * c4) = o;
   }
   if (!a.planes) return;  // uniform
   __syncthreads();

@@ -296,3 +296,28 @@ def test_model_prefill_continues_cache_and_reduced_terms(E, pkg, oracle):
         m.prefill(toks, cfg["max_pos"] - 10)  # runs past the cache
     m.free()
     om.close()
+
+
+def test_prefill_attention_writes_the_gemm_planes_bit_identically(E, pkg, monkeypatch):
+    """The prefill attention kernel writes the attn_output GEMM's activation planes itself (no split launch); every logit of
+    an all-logits prefill -- one call, and a second call appending to the cache, with 6 and 3 MFMA terms -- is bit for bit
+    what TL_ATTN_PLANES=0 (attention -> float rows -> split launch) gives."""
+    rng = np.random.default_rng(12)
+    for shape, mix, n in (("tiny-gqa", "q4_k_m", 150), ("tiny-tp", "q6_k", 77)):
+        cfg, tensors = pkg.synth.build_model(shape, mix, seed=4)
+        toks = rng.integers(0, cfg["vocab"], n).astype(np.int32)
+        got = {}
+        for ap in ("0", "1"):
+            monkeypatch.setenv("TL_ATTN_PLANES", ap)
+            m = E.Model(cfg).load(tensors)
+            out = []
+            for terms in (6, 3):
+                m.reset_kv()
+                m.set_prefill(terms=terms, min_batch=8)
+                _, a = m.prefill(toks[:n - 40], 0, all_logits=True)
+                _, b = m.prefill(toks[n - 40:], n - 40, all_logits=True)
+                out += [np.array(a), np.array(b)]
+            got[ap] = out
+            m.free()
+        for a, b in zip(got["0"], got["1"]):
+            assert a.shape == b.shape and np.array_equal(a, b), (shape, np.abs(a - b).max())

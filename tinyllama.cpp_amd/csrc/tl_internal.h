@@ -272,8 +272,10 @@ int tl_launch_ksplit_reduce(const GemmParts& g, const float* resid, float* y, hi
 
 // causal prefill attention on the FP32 matrix instruction (tl_prefill.hip)
 bool tl_attn_prefill_mfma_supported(int nh, int nkv, int hd);
+// planes != NULL: the output as the attn_output GEMM's activation planes (tl_launch_split's layout) instead of `out`
 int tl_launch_attn_prefill_mfma(const float* q, const float* kc, const float* vc, float* out, int T, int start_pos,
-                                int nh, int nkv, int hd, float scale, hipStream_t s);
+                                int nh, int nkv, int hd, float scale, hipStream_t s, void* planes = nullptr,
+                                size_t plane_stride = 0, int terms = 0);
 
 // on-device temperature / top-k / top-p sampler (tl_sample.hip)
 constexpr int TL_SAMPLE_MAX_TOP_K = 1024;

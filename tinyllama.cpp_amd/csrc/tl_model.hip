@@ -1345,9 +1345,17 @@ static int prefill_attn_half(tl_model* m, int l, int T, int start_pos, hipStream
     TL_TRY(tl_update_kv_cache_batch(m->kc(l), p.kb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
     TL_TRY(tl_update_kv_cache_batch(m->vc(l), p.vb, start_pos, T, m->nkv_l, hd, c.max_position_embeddings, s));
   }
-  TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
-                                    m->nkv_l, hd, scale, s));
-  TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+  // the attention output goes straight into the planes of the attn_output GEMM where the MFMA kernel serves the head shape
+  // (no split launch; TL_ATTN_PLANES=0 keeps the launch, for A/B runs and the bit-identity test)
+  const char* ap = getenv("TL_ATTN_PLANES");
+  if (tl_attn_prefill_mfma_supported(m->nh_l, m->nkv_l, hd) && !(ap && atoi(ap) == 0)) {
+    TL_TRY(tl_launch_attn_prefill_mfma(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, m->nh_l, m->nkv_l, hd, scale, s, p.planes,
+                                       ps, terms));
+  } else {
+    TL_TRY(tl_attention_batch_prefill(p.qb, m->kc(l), m->vc(l), p.ab, T, start_pos, c.max_position_embeddings, m->nh_l,
+                                      m->nkv_l, hd, scale, s));
+    TL_TRY(tl_launch_split(0, p.ab, nullptr, p.planes, ps, T, m->qd_l, terms, 0.f, s));
+  }
   return project_residual(m, L.q[TL_T_ATTN_OUTPUT], T, s);
 }
 static int prefill_mlp_half(tl_model* m, int l, int T, hipStream_t s) {

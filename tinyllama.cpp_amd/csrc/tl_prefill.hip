@@ -51,6 +51,17 @@ constexpr int PF_NW = 8;  // waves per workgroup (two per SIMD: 256 VGPRs each)
 template <int HD>
 constexpr size_t pf_lds_floats() { return (size_t)PF_NW * 32 * 3 + 32 + 32 * (size_t)(HD + 4) + (size_t)PF_NW * 32 * HD; }
 
+// planes != NULL: the output goes straight into the activation planes of the attn_output GEMM (what split_kernel<SPLIT_PLAIN>
+// would make of `out`, bit for bit: np bf16 planes [plane_stride] of the [T][nh * hd] matrix + the sums of its 32-column
+// blocks [nh * hd / 32][tpad]); `out` is then not written
+struct PfPlanes {
+  __bf16* planes;
+  size_t plane_stride;
+  float* xsum;
+  int np, tpad;
+};
+typedef __bf16 pf_bf16x8 __attribute__((ext_vector_type(8)));
+
 struct PfTile {  // one 32-query tile as this lane sees it
   int q0, qi, qpos, ntile, nact;
 };
@@ -58,7 +69,7 @@ struct PfTile {  // one 32-query tile as this lane sees it
 template <int HD>
 __global__ __launch_bounds__(64 * PF_NW) void attn_prefill_mfma_kernel(const float* __restrict__ q, const float* __restrict__ kc,
                                                                const float* __restrict__ vc, float* __restrict__ out,
-                                                               int T, int start_pos, int nh, int nkv, float scale) {
+                                                               int T, int start_pos, int nh, int nkv, float scale, PfPlanes pl) {
   constexpr int HH = HD / 2;   // d range of a lane half
   constexpr int DB = HD / 32;  // 32-wide d blocks of the output
   extern __shared__ __attribute__((aligned(16))) float pf_sm[];
@@ -284,18 +295,47 @@ __global__ __launch_bounds__(64 * PF_NW) void attn_prefill_mfma_kernel(const flo
     if (next_q) store_q(tB, 64 * nact, qtmp);
     __syncthreads();
     PFS(9 + 12 * ph);
-    // ---- out[q][d] = O / (L + 1e-9): the surviving threads over 32 x HD / 4 quads, slots summed in wave order -----------
-    for (int i = threadIdx.x; i < 32 * (HD / 4); i += 64 * nact) {
-      const int row = i / (HD / 4), c4 = i % (HD / 4);
-      if (t.q0 + row >= T) continue;
-      f32x4 O = *reinterpret_cast<const f32x4*>(sm_o + row * HD + 4 * c4);
+    // ---- out[q][d] = O / (L + 1e-9): the surviving threads over 32 x HD / 8 column octets, slots summed in wave order; or
+    //      the GEMM planes of those eight columns (split_kernel<SPLIT_PLAIN>'s body: 8 columns per thread, the sum of a
+    //      32-column block over 4 neighbouring threads) ---------------------------------------------------------------
+    for (int i = threadIdx.x; i < 32 * (HD / 8); i += 64 * nact) {
+      const int row = i / (HD / 8), c8 = i % (HD / 8);
+      const bool live = t.q0 + row < T;
+      f32x4 lo = *reinterpret_cast<const f32x4*>(sm_o + row * HD + 8 * c8);
+      f32x4 hi = *reinterpret_cast<const f32x4*>(sm_o + row * HD + 8 * c8 + 4);
       for (int w = 1; w < nact; ++w) {
-        const f32x4 x = *reinterpret_cast<const f32x4*>(sm_o + (size_t)w * 32 * HD + row * HD + 4 * c4);
-        O[0] += x[0]; O[1] += x[1]; O[2] += x[2]; O[3] += x[3];
+        const f32x4 x = *reinterpret_cast<const f32x4*>(sm_o + (size_t)w * 32 * HD + row * HD + 8 * c8);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(sm_o + (size_t)w * 32 * HD + row * HD + 8 * c8 + 4);
+        lo[0] += x[0]; lo[1] += x[1]; lo[2] += x[2]; lo[3] += x[3];
+        hi[0] += y[0]; hi[1] += y[1]; hi[2] += y[2]; hi[3] += y[3];
       }
       const float inv = sm_inv[row];
-      O[0] *= inv; O[1] *= inv; O[2] *= inv; O[3] *= inv;
-      *reinterpret_cast<f32x4*>(out + ((size_t)(t.q0 + row) * nh + head) * HD + 4 * c4) = O;
+      lo[0] *= inv; lo[1] *= inv; lo[2] *= inv; lo[3] *= inv;
+      hi[0] *= inv; hi[1] *= inv; hi[2] *= inv; hi[3] *= inv;
+      if (!pl.planes) {
+        if (live) {
+          float* op = out + ((size_t)(t.q0 + row) * nh + head) * HD + 8 * c8;
+          *reinterpret_cast<f32x4*>(op) = lo;
+          *reinterpret_cast<f32x4*>(op + 4) = hi;
+        }
+        continue;  // (uniform: pl is a kernel argument)
+      }
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      float bs = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+      bs += __shfl_xor(bs, 1);  // (the four threads of a block are neighbours of one row: all here together)
+      bs += __shfl_xor(bs, 2);
+      if (!live) continue;
+      const int tok = t.q0 + row, K = nh * HD, i0 = head * HD + 8 * c8;
+      if ((c8 & 3) == 0) pl.xsum[(size_t)(i0 >> 5) * pl.tpad + tok] = bs;
+      for (int p = 0; p < pl.np; ++p) {
+        pf_bf16x8 b;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          b[e] = (__bf16)v[e];
+          v[e] -= (float)b[e];
+        }
+        *reinterpret_cast<pf_bf16x8*>(pl.planes + p * pl.plane_stride + (size_t)tok * K + i0) = b;
+      }
     }
     PFS(10 + 12 * ph);
   }
@@ -317,18 +357,28 @@ bool tl_attn_prefill_mfma_supported(int nh, int nkv, int hd) {
 
 // q [T][nh][hd] (rotated), caches [max_seq][nkv][hd] already holding positions 0..start_pos+T-1, out [T][nh][hd]
 int tl_launch_attn_prefill_mfma(const float* q, const float* kc, const float* vc, float* out, int T, int start_pos,
-                                int nh, int nkv, int hd, float scale, hipStream_t s) {
+                                int nh, int nkv, int hd, float scale, hipStream_t s, void* planes, size_t plane_stride,
+                                int terms) {
   TL_REQUIRE(tl_attn_prefill_mfma_supported(nh, nkv, hd), "tl_launch_attn_prefill_mfma: unsupported head shape");
   if (T == 0) return 0;
+  PfPlanes pl = {nullptr, 0, nullptr, 0, 0};
+  if (planes) {  // layout as tl_launch_split makes it: three bf16 planes, then the block sums
+    TL_REQUIRE(plane_stride >= tl_gemm_padded_tokens(T) * (size_t)nh * hd, "prefill attention: activation planes too small");
+    pl.planes = static_cast<__bf16*>(planes);
+    pl.plane_stride = plane_stride;
+    pl.xsum = reinterpret_cast<float*>(pl.planes + 3 * plane_stride);
+    pl.np = terms == 1 ? 1 : terms == 3 ? 2 : 3;
+    pl.tpad = (int)tl_gemm_padded_tokens(T);
+  }
   const dim3 grid((((T + 31) / 32 + 1) / 2) * nh), block(64 * PF_NW);
   if (hd == 128) {
     static TlDeviceOnce lds_raised;  // per kernel instantiation, per device
     TL_TRY(tl_raise_lds_limit(attn_prefill_mfma_kernel<128>, 160 * 1024, lds_raised));
-    attn_prefill_mfma_kernel<128><<<grid, block, sizeof(float) * pf_lds_floats<128>(), s>>>(q, kc, vc, out, T, start_pos, nh, nkv, scale);
+    attn_prefill_mfma_kernel<128><<<grid, block, sizeof(float) * pf_lds_floats<128>(), s>>>(q, kc, vc, out, T, start_pos, nh, nkv, scale, pl);
   } else {
     static TlDeviceOnce lds_raised;
     TL_TRY(tl_raise_lds_limit(attn_prefill_mfma_kernel<64>, 160 * 1024, lds_raised));
-    attn_prefill_mfma_kernel<64><<<grid, block, sizeof(float) * pf_lds_floats<64>(), s>>>(q, kc, vc, out, T, start_pos, nh, nkv, scale);
+    attn_prefill_mfma_kernel<64><<<grid, block, sizeof(float) * pf_lds_floats<64>(), s>>>(q, kc, vc, out, T, start_pos, nh, nkv, scale, pl);
   }
   TL_HIP(hipGetLastError());
   return 0;
